@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- physics steps/s of the particle step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one State::update() (state.rs:115-131): [Morton re-sort] -> pair list + sort ->
+collision-cell list -> 4 colour passes -> Verlet, over one synthetic uniform-random particle cloud
+that is already resident in HBM when the timed region starts.  Default workload = BASELINE.json
+configs[1]: 1M particles, gravity off, the reference's 3048 x 1048 world.  The 100M-particle
+configuration (configs[2]) is measured in the same run and reported under "extra_workloads".
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel: algorithmic bytes per launch
+("Kernels and rooflines") / its mean launch time from hipEvent pairs recorded on the
+library's own stream inside the timed region.  `cpu_baseline` is the CPU oracle (a port of the
+reference algorithm, oracle/gpe_oracle.c) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALGO_BYTES_PER_PARTICLE = 148    # hash 12 + sort 68 + grid 8 + collision 24 + integrate 36
+RESORT_EVERY = 240               # 4 s at 60 Hz (particle_system.rs:13-14)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
+    ap.add_argument("--mode", choices=["compat", "native"], default=os.environ.get("GPE_BENCH_MODE", "compat"))
+    ap.add_argument("--gravity", choices=["off", "on"], default="off")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 100M-particle extra workload")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-particles", type=int, default=100_000_000)
+    ap.add_argument("--extra-steps", type=int, default=20)
+    return ap.parse_args()
+
+
+def kernel_rooflines(timings, n_particles, mode):
+    """Per-kernel algorithmic traffic (bytes per launch) for the kernels this build launches."""
+    n = n_particles
+    pairs = 4 * n if mode == "compat" else n
+    table = {
+        # name: (bytes per launch, description)
+        "sort/scatter": (16 * pairs, "R key+payload 8 B, W key+payload 8 B per pair"),
+        "sort/count": (4 * pairs, "R key 4 B per pair"),
+        "Build cell ids": (12 * n + 32 * n, "R pos 8 + radius 4, W 4 cell ids + 4 object ids"),
+        "Particle integration pass": (36 * n, "R pos 8 + prev 8 + radius 4, W pos 8 + prev 8"),
+        "Collision cell count objects per chunk": (16 * n + 4 * n, "R 4N keys, W N counts"),
+        "Build collision cells": (4 * n + 16 * n + 4 * n, "R counts + keys, W ~N starts"),
+    }
+    out = {}
+    for name, (bytes_per_launch, desc) in table.items():
+        if name in timings and timings[name][1] > 0:
+            ms = timings[name][0] / timings[name][1]
+            out[name] = {"avg_ms": ms, "bytes": bytes_per_launch, "GBps": bytes_per_launch / (ms * 1e-3) / 1e9,
+                         "calls": timings[name][1], "total_ms": timings[name][0], "what": desc}
+    return out
+
+
+def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gravity, device):
+    """Returns (seconds for `steps` steps, max over ranks; timings dict of rank 0)."""
+    import numpy as np
+    world = gpe.scenes.world_for(n)
+    t0 = time.time()
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED + rank)
+    log("[rank %d] scene: %d particles in %.1f x %.1f (%.1fs)" % (rank, n, world[0], world[1], time.time() - t0))
+    g = (0.0, -9.81) if gravity == "on" else (0.0, 0.0)
+    st = gpe.State(pos, rad, world=world, gravity=g, device=device,
+                   mode=gpe.MODE_NATIVE if mode == "native" else gpe.MODE_COMPAT)
+    del pos, rad
+    dt = 1.0 / 60.0
+    st.run(dt, warmup, resort_every=RESORT_EVERY, resort_first=True)      # first frame re-sorts
+    st.ctx.sync()
+    st.ctx.set_profiling(True)
+    st.ctx.reset_timings()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st.run(dt, steps, resort_every=RESORT_EVERY, resort_first=False)
+    st.ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timings = st.ctx.timings()
+    p = st.positions()
+    assert np.isfinite(p).all(), "non-finite positions after the run"
+    st.close()
+    return elapsed, timings, world
+
+
+def cpu_baseline(gpe, n, budget_s=15.0):
+    """The CPU oracle (port of the reference algorithm) on this box's host cores: single thread."""
+    from oracle import oracle as orc      # checker / baseline only
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    sim = orc.Sim(pos, rad, orc.default_params(world[0], world[1], 0.5))
+    sim.step(1.0 / 60.0, resort=True)     # warm-up step (includes the re-sort)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        sim.step(1.0 / 60.0, resort=False)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 1000:
+            break
+    sim.close()
+    return {"value": steps / el, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "%d particles x %d steps of oracle/gpe_oracle.c (reference algorithm: 4N pairs, LSD radix "
+                      "sort, chunk count, scan, 4 colour passes, Verlet), 1 thread of %d host cores"
+                      % (n, steps, os.cpu_count() or 0)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus and world_size > 1:
+        log("warning: WORLD_SIZE=%d but --gpus %d" % (world_size, args.gpus))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    gpe = importlib.import_module("gpu-physics-engine_amd")
+    gpe._lib.load()
+
+    n = args.particles
+    elapsed, timings, world = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
+                                           args.mode, args.gravity, local_rank)
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    steps_per_s = args.steps / elapsed
+    roofs = kernel_rooflines(timings, n, args.mode)
+    for name, (tot, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0]):
+        extra = ""
+        if name in roofs:
+            extra = "  %.0f GB/s algorithmic" % roofs[name]["GBps"]
+        log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
+    dom = max(roofs.items(), key=lambda kv: kv[1]["total_ms"]) if roofs else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if dom and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.mode, {}).get(dom[0], {}).get(str(n))
+        except Exception:
+            traffic = None
+    roofline = None
+    if dom:
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(dom[1]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "bytes_per_launch": dom[1]["bytes"], "avg_launch_ms": round(dom[1]["avg_ms"], 5),
+                    "launches": dom[1]["calls"]}
+
+    result = {
+        "metric": "physics_steps_per_sec", "value": round(steps_per_s * 1.0, 3), "unit": "steps/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u32",
+        "data": "synthetic",
+        "config": {"workload": "%d particles per GPU, gravity %s, world %.1f x %.1f, radius 0.5, uniform random "
+                               "(BASELINE.json configs[1] at 1M)" % (n, args.gravity, world[0], world[1]),
+                   "particles_per_gpu": n, "mode": args.mode, "resort_every": RESORT_EVERY, "dt": 1.0 / 60.0,
+                   "particle_steps_per_sec": round(steps_per_s * n * args.gpus, 1),
+                   "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * n * args.gpus * steps_per_s / 1e9, 2),
+                   "step_frac_of_hbm_roofline": round(ALGO_BYTES_PER_PARTICLE * n * steps_per_s / 1e9 / HBM_PEAK_GBS, 5),
+                   "reference_frame_ms_rx6800xt_incl_render": 3.66 if n == 1_000_000 else None},
+        "roofline": roofline,
+    }
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle, 1 thread) ...")
+        result["cpu_baseline"] = cpu_baseline(gpe, min(n, 1_000_000))
+        result["cpu_baseline"]["value"] = round(result["cpu_baseline"]["value"], 4)
+    if args.gpus == 1 and not args.no_extra and args.extra_particles != n:
+        ne = args.extra_particles
+        log("extra workload: %d particles, gravity on ..." % ne)
+        el2, tim2, world2 = run_workload(gpe, torch, None, 0, 1, ne, args.extra_steps, 5, args.mode, "on", local_rank)
+        sps2 = args.extra_steps / el2
+        roofs2 = kernel_rooflines(tim2, ne, args.mode)
+        for name, (tot, calls) in sorted(tim2.items(), key=lambda kv: -kv[1][0]):
+            extra = "  %.0f GB/s algorithmic" % roofs2[name]["GBps"] if name in roofs2 else ""
+            log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
+        dom2 = max(roofs2.items(), key=lambda kv: kv[1]["total_ms"]) if roofs2 else None
+        result["extra_workloads"] = [{
+            "workload": "%d particles, gravity on (0,-9.81), world %.1f x %.1f (BASELINE.json configs[2])" % (ne, world2[0], world2[1]),
+            "steps": args.extra_steps, "steps_per_sec": round(sps2, 3), "ms_per_step": round(1e3 / sps2, 4),
+            "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * ne * sps2 / 1e9, 1),
+            "step_frac_of_hbm_roofline": round(ALGO_BYTES_PER_PARTICLE * ne * sps2 / 1e9 / HBM_PEAK_GBS, 4),
+            "dominant_kernel": dom2[0] if dom2 else None,
+            "dominant_kernel_GBps": round(dom2[1]["GBps"], 1) if dom2 else None,
+            "dominant_kernel_frac": round(dom2[1]["GBps"] / HBM_PEAK_GBS, 4) if dom2 else None,
+        }]
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

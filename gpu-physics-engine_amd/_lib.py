@@ -1,0 +1,120 @@
+"""ctypes binding of libgpe.so (include/gpe.h).  No torch, no numpy arrays in the signatures:
+plain pointers and sizes, exactly what a Rust `extern "C"` block would bind."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpe.so")
+
+GPE_OK = 0
+GPE_ERR_INVALID_ARG = -1
+GPE_ERR_HIP = -2
+GPE_ERR_OOM = -3
+GPE_ERR_STATE = -4
+GPE_ERR_UNSUPPORTED = -5
+GPE_ERR_NO_DEVICE = -6
+
+MODE_COMPAT = 0
+MODE_NATIVE = 1
+STEP_RESORT = 1
+
+UNUSED_CELL_ID = 0xFFFFFFFF
+MAX_CELLS_PER_OBJECT = 4
+COUNTING_CHUNK_SIZE = 4
+
+# gpe_array
+POS, PREV, RADIUS, HOME_CELL_IDS, PARTICLE_IDS, CELL_IDS, OBJECT_IDS, COLLISION_CELLS, \
+    NUM_COLLISION_CELLS, CHUNK_OBJ_COUNT, INDIRECT_ARGS = range(11)
+
+
+class GpeConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32),
+        ("world_width", C.c_float), ("world_height", C.c_float),
+        ("gravity_x", C.c_float), ("gravity_y", C.c_float),
+        ("cell_size_multiplier", C.c_float), ("stiffness", C.c_float),
+        ("mouse_strength", C.c_float), ("mode", C.c_uint32), ("profiling", C.c_uint32),
+        ("reserved", C.c_uint32 * 5),
+    ]
+
+
+class GpeTiming(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("total_ms", C.c_double), ("calls", C.c_uint64)]
+
+
+class GpeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("gpe status %d: %s" % (status, message))
+        self.status = status
+
+
+# every symbol include/gpe.h declares: (name, restype, argtypes)
+_VP, _U64, _U32, _I32, _F = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_float
+SYMBOLS = [
+    ("gpe_abi_version", _U32, []),
+    ("gpe_config_default", _I32, [C.POINTER(GpeConfig)]),
+    ("gpe_create", _I32, [C.POINTER(GpeConfig), C.POINTER(_VP)]),
+    ("gpe_destroy", _I32, [_VP]),
+    ("gpe_last_error", C.c_char_p, [_VP]),
+    ("gpe_set_particles", _I32, [_VP, _VP, _VP, _VP, _U64]),
+    ("gpe_add_particles", _I32, [_VP, _VP, _VP, _U64]),
+    ("gpe_len", _I32, [_VP, C.POINTER(_U64)]),
+    ("gpe_max_radius", _I32, [_VP, C.POINTER(_F)]),
+    ("gpe_morton_resort", _I32, [_VP]),
+    ("gpe_integrate", _I32, [_VP, _F]),
+    ("gpe_set_mouse", _I32, [_VP, _I32, _F, _F]),
+    ("gpe_set_world", _I32, [_VP, _F, _F]),
+    ("gpe_set_gravity", _I32, [_VP, _F, _F]),
+    ("gpe_compute_cell_size", _F, [_F]),
+    ("gpe_grid_set_max_radius", _I32, [_VP, _F]),
+    ("gpe_cell_size", _I32, [_VP, C.POINTER(_F)]),
+    ("gpe_grid_build", _I32, [_VP]),
+    ("gpe_grid_sort", _I32, [_VP]),
+    ("gpe_grid_update", _I32, [_VP]),
+    ("gpe_solve_collisions", _I32, [_VP]),
+    ("gpe_build_collision_cells", _I32, [_VP]),
+    ("gpe_step", _I32, [_VP, _F, _U32]),
+    ("gpe_run", _I32, [_VP, _F, _U64, _U64, _I32]),
+    ("gpe_sync", _I32, [_VP]),
+    ("gpe_set_mode", _I32, [_VP, _U32]),
+    ("gpe_download", _I32, [_VP, C.c_int, _VP, _U64]),
+    ("gpe_array_bytes", _I32, [_VP, C.c_int, C.POINTER(_U64)]),
+    ("gpe_device_ptr", _I32, [_VP, C.c_int, C.POINTER(_VP), C.POINTER(_U64)]),
+    ("gpe_buffer_alloc", _I32, [_VP, _U64, C.POINTER(_VP)]),
+    ("gpe_buffer_free", _I32, [_VP, _VP]),
+    ("gpe_buffer_upload", _I32, [_VP, _VP, _VP, _U64]),
+    ("gpe_buffer_download", _I32, [_VP, _VP, _VP, _U64]),
+    ("gpe_sort_pairs_u32", _I32, [_VP, _VP, _VP, _U64]),
+    ("gpe_sort_histogram_u32", _I32, [_VP, _VP, _U64, _U32, _VP]),
+    ("gpe_sort_scatter_pass_u32", _I32, [_VP, _VP, _VP, _VP, _VP, _U64, _U32]),
+    ("gpe_inclusive_scan_u32", _I32, [_VP, _VP, _U64]),
+    ("gpe_set_profiling", _I32, [_VP, _U32]),
+    ("gpe_reset_timings", _I32, [_VP]),
+    ("gpe_get_timings", _I32, [_VP, C.POINTER(GpeTiming), C.POINTER(_U32)]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libgpe.so.  There is no CPU or pure-Python fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python gpu-physics-engine_amd/build.py` "
+            "(or __graft_entry__.build()); the HIP extension is the only implementation" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, ctx=None):
+    if status != GPE_OK:
+        msg = load().gpe_last_error(ctx)
+        raise GpeError(status, msg.decode() if msg else "")

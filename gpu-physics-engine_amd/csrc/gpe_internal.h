@@ -1,0 +1,261 @@
+// gpe_internal.h -- shared declarations of the gfx950 implementation behind include/gpe.h.
+// HIP for CDNA4 only: wave64, no portability layers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gpe.h"
+
+namespace gpe {
+
+constexpr uint32_t kUnused = GPE_UNUSED_CELL_ID;
+constexpr int kWave = 64;
+// Streaming kernels cap their grid and grid-stride the rest (256 CUs x 8 blocks).
+constexpr int kStreamBlock = 256;
+constexpr int kMaxStreamGrid = 256 * 8;
+
+inline int stream_grid(uint64_t items, int per_block = kStreamBlock)
+{
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)kMaxStreamGrid) g = kMaxStreamGrid;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers shared by several kernels (each restates a WGSL helper; citations are into
+// /root/reference/src)
+// ------------------------------------------------------------------------------------------------
+// grid.wgsl:101-108 / home_cell_ids.wgsl:38-45
+__device__ __forceinline__ uint32_t split_by_bits(uint32_t n)
+{
+    uint32_t x = n & 0x0000FFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+// grid.wgsl:112-114 ; u32(i32) is a bit cast
+__device__ __forceinline__ uint32_t morton_encode(int32_t x, int32_t y)
+{
+    return split_by_bits((uint32_t)x) | (split_by_bits((uint32_t)y) << 1);
+}
+// collision_solver.wgsl:123-130
+__device__ __forceinline__ uint32_t unsplit_by_bits(uint32_t n)
+{
+    uint32_t x = n & 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+// collision_solver.wgsl:55-58
+__device__ __forceinline__ uint32_t cell_color(uint32_t cell_hash)
+{
+    return 1u + (unsplit_by_bits(cell_hash) & 1u) + (unsplit_by_bits(cell_hash >> 1) & 1u) * 2u;
+}
+// WGSL i32(f32): truncate, saturate, NaN -> 0.  v_cvt_i32_f32 does exactly that on gfx950, but
+// the C++ cast is undefined out of range, so spell it out (the compiler folds it back).
+__device__ __forceinline__ int32_t f32_to_i32_sat(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 0x7fffffff;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)f;
+}
+// grid.wgsl:53 / home_cell_ids.wgsl:27 : vec2<i32>(floor(pos / cell_size)) -- a true division.
+__device__ __forceinline__ int32_t cell_coord(float p, float cell_size)
+{
+    return f32_to_i32_sat(floorf(p / cell_size));
+}
+// WGSL clamp(e, lo, hi) = min(max(e, lo), hi), written with compares so NaN/-0 behave as in the oracle
+__device__ __forceinline__ float clamp_f(float x, float lo, float hi)
+{
+    float m = (x > lo) ? x : lo;
+    return (m < hi) ? m : hi;
+}
+// grid.wgsl:117-129 is_obj_in_cell
+__device__ __forceinline__ bool is_obj_in_cell(float px, float py, float sq_radius, int32_t cx,
+                                               int32_t cy, float cs)
+{
+    float lo_x = (float)cx * cs, lo_y = (float)cy * cs;
+    float hi_x = lo_x + cs, hi_y = lo_y + cs;
+    float qx = clamp_f(px, lo_x, hi_x), qy = clamp_f(py, lo_y, hi_y);
+    float dx = px - qx, dy = py - qy;
+    float dist_sq = dx * dx + dy * dy;
+    return dist_sq < sq_radius;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 / block helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// number of set bits of `m` strictly below this lane
+__device__ __forceinline__ uint32_t popc_below_lane(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; `total` receives the block sum.
+// s_w: >= 4 words of LDS scratch.  Contains __syncthreads (all 256 threads must call it).
+__device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t *s_w, uint32_t *total)
+{
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    uint32_t base = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+    if (total) *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side context
+// ------------------------------------------------------------------------------------------------
+struct ScopeStat {
+    std::string name;
+    double total_ms = 0.0;
+    uint64_t calls = 0;
+};
+struct PendingEvent {
+    int stat;
+    hipEvent_t start, stop;
+};
+
+struct ScanWorkspace {           // reduce-then-scan tile sums, one array per recursion level
+    std::vector<uint32_t *> level;
+    std::vector<uint64_t> cap;
+};
+
+struct SortWorkspace {
+    uint32_t *keys_b = nullptr, *vals_b = nullptr;   // ping-pong partners, cap entries each
+    uint64_t cap = 0;
+    uint32_t *counts = nullptr;                      // [256][tiles] per-tile digit counts
+    uint64_t counts_cap = 0;
+    uint32_t *hist4 = nullptr;                       // 4 x 256 global digit histograms
+};
+
+}  // namespace gpe
+
+struct gpe_ctx {
+    gpe_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    uint64_t n = 0;          // particles
+    uint64_t cap = 0;        // allocated particle capacity
+    float max_radius = 0.f;  // ParticleSystem::max_radius
+    float grid_max_radius = 0.f;
+    float cell_size = 0.f;
+    int32_t mouse_pressed = 0;
+    float mouse_x = 0.f, mouse_y = 0.f;
+
+    // particle_buffers.rs:4-10, two sets (particle_system.rs:17-18); colours are render-only
+    float2 *pos = nullptr, *prev = nullptr;
+    float *radius = nullptr;
+    float2 *pos_copy = nullptr, *prev_copy = nullptr;
+    float *radius_copy = nullptr;
+    uint32_t *home_cell_ids = nullptr, *particle_ids = nullptr;   // particle_sort.rs:29-33
+    // grid.rs:36-40 GridBuffers (4 slots per particle)
+    uint32_t *cell_ids = nullptr, *object_ids = nullptr;
+    // collision_cell_buffers.rs:6-10
+    uint32_t *chunk_obj_count = nullptr;   // ceil(4n/4) = n entries
+    uint32_t *collision_cells = nullptr;   // 4n entries
+    uint32_t *indirect_args = nullptr;     // 3 entries (+1: K)
+
+    gpe::SortWorkspace sort_ws;
+    gpe::ScanWorkspace scan_ws;
+
+    // profiling
+    bool profiling = false;
+    std::vector<gpe::ScopeStat> stats;
+    std::vector<gpe::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace gpe {
+
+// error plumbing -----------------------------------------------------------------------------
+gpe_status fail(gpe_ctx *ctx, gpe_status code, const std::string &msg);
+#define GPE_HIP(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return gpe::fail((ctx), GPE_ERR_HIP,                                                \
+                             std::string(#expr) + ": " + hipGetErrorName(_e) + " (" +           \
+                                 hipGetErrorString(_e) + ")");                                  \
+    } while (0)
+#define GPE_TRY(expr)                                                                           \
+    do {                                                                                        \
+        gpe_status _s = (expr);                                                                 \
+        if (_s != GPE_OK) return _s;                                                            \
+    } while (0)
+
+// profiling scope: a hipEvent pair on ctx->stream when ctx->profiling, else nothing.
+class Scope {
+   public:
+    Scope(gpe_ctx *ctx, const char *name);
+    ~Scope();
+
+   private:
+    gpe_ctx *ctx_;
+    int stat_ = -1;
+    hipEvent_t start_ = nullptr;
+};
+
+// kernel launchers (one translation unit each) --------------------------------------------------
+// particles
+gpe_status launch_home_cell_ids(gpe_ctx *c, const float2 *pos, uint64_t n, float cell_size,
+                                uint32_t *home, uint32_t *ids);
+gpe_status launch_rearrange(gpe_ctx *c, const float2 *pos, const float2 *prev, const float *radius,
+                            const uint32_t *ids, uint64_t n, float2 *pos_out, float2 *prev_out,
+                            float *radius_out);
+gpe_status launch_verlet(gpe_ctx *c, float2 *pos, float2 *prev, const float *radius, uint64_t n,
+                         float dt);
+// grid
+gpe_status launch_build_cell_ids(gpe_ctx *c, const float2 *pos, const float *radius, uint64_t n,
+                                 float cell_size, uint32_t *cell_ids, uint32_t *object_ids);
+// sort / scan
+gpe_status sort_reserve(gpe_ctx *c, uint64_t n);
+gpe_status sort_pairs(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint64_t n);
+gpe_status sort_histogram(gpe_ctx *c, const uint32_t *keys, uint64_t n, uint32_t shift, uint32_t *hist256);
+gpe_status sort_scatter_pass(gpe_ctx *c, const uint32_t *ka, const uint32_t *va, uint32_t *kb,
+                             uint32_t *vb, uint64_t n, uint32_t shift);
+gpe_status scan_reserve(gpe_ctx *c, uint64_t n);
+gpe_status inclusive_scan(gpe_ctx *c, uint32_t *data, uint64_t n);
+void sort_release(gpe_ctx *c);
+void scan_release(gpe_ctx *c);
+// collision cells + solver
+gpe_status launch_count_chunks(gpe_ctx *c, const uint32_t *cell_ids, uint64_t total, uint32_t *chunk_counts);
+gpe_status launch_build_collision_cells(gpe_ctx *c, const uint32_t *cell_ids, uint64_t total,
+                                        const uint32_t *scanned, uint64_t num_chunks,
+                                        uint32_t *collision_cells, uint32_t *indirect_args);
+gpe_status launch_solve_color(gpe_ctx *c, const uint32_t *collision_cells, const uint32_t *scanned,
+                              uint64_t num_chunks, const uint32_t *cell_ids, const uint32_t *object_ids,
+                              uint64_t total, float2 *pos, const float *radius, float stiffness,
+                              uint32_t color);
+
+}  // namespace gpe

@@ -1,0 +1,191 @@
+/*
+ * gpe.h -- C-ABI of the MI355X-native particle step (libgpe.so).
+ *
+ * Drop-in boundary for the per-timestep particle pipeline of MarcVivas/gpu-physics-engine:
+ * everything State::update() (src/state.rs:115-131) calls except the camera update, i.e. the
+ * module API of src/particles, src/grid, src/physics and the two GPU primitives in src/utils.
+ * The reference exports no FFI of its own (Cargo.toml:6-7 builds cdylib+rlib with nothing
+ * extern "C"), so each entry point below names the Rust method a host shim would forward to it.
+ * Citations are relative to /root/reference/src.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; positions are interleaved (x,y) f32 pairs (glam::Vec2).
+ *  - the library owns all device memory; the caller owns every host array passed in or out.
+ *  - every function returns gpe_status (0 = OK, negative = error) and never unwinds;
+ *    gpe_last_error() gives the message of the last failure on that context (or globally when
+ *    ctx is NULL).  The reference unwrap()s/panics instead (gpu_buffer.rs:266-268).
+ *  - one in-order hipStream per context; calls on one context are not re-entrant.
+ *    gpe_step/gpe_run and the per-module calls are asynchronous; gpe_download/gpe_sync block.
+ */
+#ifndef GPE_H
+#define GPE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPE_ABI_VERSION 1u
+#define GPE_UNUSED_CELL_ID 0xffffffffu    /* grid/grid.rs:22  UNUSED_CELL_ID            */
+#define GPE_MAX_CELLS_PER_OBJECT 4u       /* grid/grid.rs:18  MAX_CELLS_PER_OBJECT      */
+#define GPE_COUNTING_CHUNK_SIZE 4u        /* physics/collision_cell_builder.rs:13       */
+
+typedef struct gpe_ctx gpe_ctx;
+typedef int32_t gpe_status;
+
+enum {
+    GPE_OK = 0,
+    GPE_ERR_INVALID_ARG = -1,
+    GPE_ERR_HIP = -2,          /* a HIP runtime call failed (message has the hipError name)  */
+    GPE_ERR_OOM = -3,
+    GPE_ERR_STATE = -4,        /* call order violated (e.g. step before set_particles)       */
+    GPE_ERR_UNSUPPORTED = -5,
+    GPE_ERR_NO_DEVICE = -6     /* no gfx950 device visible: there is NO CPU fallback         */
+};
+
+/* Which kernels gpe_step() runs.  Both produce identical positions (tests/test_parity_gpu.py).
+ * COMPAT materialises the reference's own intermediate buffers every step (4N (cell,object)
+ * pairs, chunk counts, collision-cell list) -- needed for bit-exact comparison with the
+ * reference tests.  NATIVE is the MI355X design: N-key sort + LDS-staged cell windows. */
+enum { GPE_MODE_COMPAT = 0, GPE_MODE_NATIVE = 1 };
+
+enum { GPE_STEP_RESORT = 1u };            /* gpe_step flags: Morton re-sort first (state.rs:122) */
+
+typedef struct gpe_config {
+    uint32_t struct_size;          /* = sizeof(gpe_config), for ABI growth                    */
+    int32_t  device;               /* HIP device ordinal, -1 = current device                 */
+    float    world_width;          /* state.rs:35  (3048)                                     */
+    float    world_height;         /* state.rs:35  (1048)                                     */
+    float    gravity_x;            /* particle_integration.wgsl:21 FORCE_OF_GRAVITY (0,0)     */
+    float    gravity_y;
+    float    cell_size_multiplier; /* grid.rs:20  CELL_SIZE_MULTIPLIER = 2.2                  */
+    float    stiffness;            /* collision_solver.wgsl:2  STIFFNESS = 0.6                */
+    float    mouse_strength;       /* particle_integration.wgsl:22  = 150                     */
+    uint32_t mode;                 /* GPE_MODE_*                                              */
+    uint32_t profiling;            /* 1: hipEvent pair around every scope (gpe_get_timings)   */
+    uint32_t reserved[5];
+} gpe_config;
+
+/* Fills *cfg with the reference's compile-time constants. */
+gpe_status gpe_config_default(gpe_config *cfg);
+
+/* State::new (state.rs:34-70) minus window/renderer: creates the HIP context (stream, events).
+ * Fails with GPE_ERR_NO_DEVICE when no GPU is visible. */
+gpe_status gpe_create(const gpe_config *cfg, gpe_ctx **out);
+gpe_status gpe_destroy(gpe_ctx *ctx);
+const char *gpe_last_error(const gpe_ctx *ctx);
+uint32_t gpe_abi_version(void);
+
+/* ---- particles (src/particles/particle_system.rs) ----------------------------------------- */
+/* ParticleSystem::new_from_buffers (:49-99) / generate_initial_particles (:102-161).
+ * prev_xy == NULL => previous = current (zero velocity, :126-127).  Also (re)creates the Grid
+ * (grid.rs:74-149) and CollisionSystem (collision_system.rs:14-22) buffers for n particles and
+ * sets max_radius = the radius of largest magnitude (:51). */
+gpe_status gpe_set_particles(gpe_ctx *ctx, const float *pos_xy, const float *prev_xy,
+                             const float *radius, uint64_t n);
+/* ParticleSystem::add_particles (:163-220) + Grid::refresh_grid (grid.rs:265-291) +
+ * CollisionSystem::refresh (collision_system.rs:24-28): append n particles (prev = pos),
+ * grow every dependent buffer (amortised x2 like gpu_buffer.rs:54-56), recompute cell size. */
+gpe_status gpe_add_particles(gpe_ctx *ctx, const float *pos_xy, const float *radius, uint64_t n);
+/* ParticleSystem::len (:275) / get_max_radius (:291) */
+gpe_status gpe_len(const gpe_ctx *ctx, uint64_t *n);
+gpe_status gpe_max_radius(const gpe_ctx *ctx, float *r);
+/* ParticleSystem::sort_by_cell_id (:236-243) -> ParticleSort::sort (particle_sort.rs:58-69):
+ * K1 home cell ids, stable sort of (home cell, particle id), K4 rearrange.  The live and copy
+ * sets are swapped instead of copied back (particle_rearrange.rs:205-238). */
+gpe_status gpe_morton_resort(gpe_ctx *ctx);
+/* ParticleSystem::update_positions (:245-247) -> K12 verlet_integration */
+gpe_status gpe_integrate(gpe_ctx *ctx, float dt);
+/* mouse_click_callback / mouse_move_callback (:221-227, particle_integration.rs:176-185) */
+gpe_status gpe_set_mouse(gpe_ctx *ctx, int32_t pressed, float x, float y);
+/* world size used by K12's wall clamp (ParticleIntegration::new, particle_integration.rs:34-48;
+ * new_from_buffers hard-codes 1920x1080, particle_system.rs:86) */
+gpe_status gpe_set_world(gpe_ctx *ctx, float width, float height);
+gpe_status gpe_set_gravity(gpe_ctx *ctx, float gx, float gy);
+
+/* ---- grid (src/grid/grid.rs) ---------------------------------------------------------------- */
+/* Grid::compute_cell_size (:159-161) */
+float gpe_compute_cell_size(float max_obj_radius);
+/* Grid::new_without_camera(ctx, max_obj_radius, &particles) (:74): override the radius the cell
+ * size is derived from (default: the particle system's max radius, Grid::new :66-71). */
+gpe_status gpe_grid_set_max_radius(gpe_ctx *ctx, float max_obj_radius);
+gpe_status gpe_cell_size(const gpe_ctx *ctx, float *cell_size);     /* Grid::cell_size (:163) */
+gpe_status gpe_grid_build(gpe_ctx *ctx);     /* Grid::build_cell_ids (:296-306), K5          */
+gpe_status gpe_grid_sort(gpe_ctx *ctx);      /* Grid::sort_map (:310-312), 4N-pair sort      */
+gpe_status gpe_grid_update(gpe_ctx *ctx);    /* Grid::update (:322-332) = build + sort       */
+
+/* ---- physics (src/physics/collision_system.rs) ---------------------------------------------- */
+/* CollisionSystem::solve_collisions (:30-39): collision-cell list (K6, scan, K10) then the four
+ * colour passes (K11).  Operates on the pair list left by gpe_grid_update. */
+gpe_status gpe_solve_collisions(gpe_ctx *ctx);
+/* CollisionCellBuilder::build_collision_cells alone (collision_cell_builder.rs:211-236) */
+gpe_status gpe_build_collision_cells(gpe_ctx *ctx);
+
+/* ---- step (src/state.rs:115-131) ------------------------------------------------------------ */
+/* One State::update(): [re-sort] -> grid update -> solve collisions -> integrate. */
+gpe_status gpe_step(gpe_ctx *ctx, float dt, uint32_t flags);
+/* `steps` updates with no host synchronisation in between; re-sorts on the first step when
+ * resort_first != 0 (particle_system.rs:45) and then every resort_every steps (0 = never;
+ * the reference re-sorts every 4 s of wall clock, particle_system.rs:13-14,229-231). */
+gpe_status gpe_run(gpe_ctx *ctx, float dt, uint64_t steps, uint64_t resort_every, int32_t resort_first);
+gpe_status gpe_sync(gpe_ctx *ctx);
+gpe_status gpe_set_mode(gpe_ctx *ctx, uint32_t mode);
+
+/* ---- downloads (GpuBuffer::download, utils/gpu_buffer.rs:96-175) ---------------------------- */
+typedef enum gpe_array {
+    GPE_POS = 0,               /* current_positions   f32[2n]   particle_system.rs:258-265        */
+    GPE_PREV = 1,              /* previous_positions  f32[2n]                                     */
+    GPE_RADIUS = 2,            /* radii               f32[n]                                      */
+    GPE_HOME_CELL_IDS = 3,     /* u32[n]   ParticleSystem::download_home_cell_ids (:250)          */
+    GPE_PARTICLE_IDS = 4,      /* u32[n]   ParticleSystem::download_particle_ids (:254)           */
+    GPE_CELL_IDS = 5,          /* u32[4n]  Grid::download_cell_ids (grid.rs:314)                  */
+    GPE_OBJECT_IDS = 6,        /* u32[4n]  Grid::download_object_ids (grid.rs:318)                */
+    GPE_COLLISION_CELLS = 7,   /* u32[4n]  CollisionSystem::download_collision_cells (:41)        */
+    GPE_NUM_COLLISION_CELLS = 8, /* u32[1] last element of the scanned chunk counts               */
+    GPE_CHUNK_OBJ_COUNT = 9,   /* u32[n]   CollisionCellBuilder::chunk_obj_count (scanned)        */
+    GPE_INDIRECT_ARGS = 10     /* u32[3]   collision_cell_builder.wgsl:96-109                     */
+} gpe_array;
+/* Blocks until the stream is idle, then copies exactly `bytes` (must equal the array's size). */
+gpe_status gpe_download(gpe_ctx *ctx, gpe_array what, void *dst, uint64_t bytes);
+gpe_status gpe_array_bytes(const gpe_ctx *ctx, gpe_array what, uint64_t *bytes);
+/* Render hand-off (particle_drawer.wgsl:11-13 reads these three as storage buffers): the device
+ * pointer stays valid until the next set/add_particles or morton_resort. */
+gpe_status gpe_device_ptr(gpe_ctx *ctx, gpe_array what, void **device_ptr, uint64_t *bytes);
+
+/* ---- GPU primitives (src/utils/radix_sort, src/utils/prefix_sum) ----------------------------- */
+/* GpuBuffer<u32> stand-in for the primitive tests (utils/gpu_buffer.rs:31-47,96-175). */
+gpe_status gpe_buffer_alloc(gpe_ctx *ctx, uint64_t bytes, void **device_ptr);
+gpe_status gpe_buffer_free(gpe_ctx *ctx, void *device_ptr);
+gpe_status gpe_buffer_upload(gpe_ctx *ctx, void *device_ptr, const void *src, uint64_t bytes);
+gpe_status gpe_buffer_download(gpe_ctx *ctx, const void *device_ptr, void *dst, uint64_t bytes);
+/* GPUSorter::sort (radix_sort.rs:199-217): stable ascending sort of n (u32 key, u32 payload)
+ * pairs, result in the caller's buffers.  Device pointers. */
+gpe_status gpe_sort_pairs_u32(gpe_ctx *ctx, uint32_t *d_keys, uint32_t *d_payload, uint64_t n);
+/* GPUSorter::build_histogram (radix_sort.rs:180-188): 256-bin histogram of (key >> shift) & 255
+ * over all n keys (the reference keeps one per workgroup; with n <= 11520 there is one). */
+gpe_status gpe_sort_histogram_u32(gpe_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t shift,
+                                  uint32_t *d_hist256);
+/* GPUSorter::scatter (radix_sort.rs:190-198): ONE stable pass on the 8-bit digit at `shift`,
+ * from (keys_a, payload_a) into (keys_b, payload_b). */
+gpe_status gpe_sort_scatter_pass_u32(gpe_ctx *ctx, const uint32_t *d_keys_a, const uint32_t *d_payload_a,
+                                     uint32_t *d_keys_b, uint32_t *d_payload_b, uint64_t n, uint32_t shift);
+/* PrefixSum::execute (prefix_sum.rs:143-160): in-place inclusive u32 scan, wrap-around add. */
+gpe_status gpe_inclusive_scan_u32(gpe_ctx *ctx, uint32_t *d_data, uint64_t n);
+
+/* ---- profiling (wgpu_profiler scopes threaded through every reference call) ------------------ */
+typedef struct gpe_timing {
+    char     name[64];    /* the reference's scope label, e.g. "Sort map" (grid.rs:329); kernel-level
+                             entries are "<scope>/<kernel>"                                   */
+    double   total_ms;    /* sum over calls since the last gpe_reset_timings                  */
+    uint64_t calls;
+} gpe_timing;
+gpe_status gpe_set_profiling(gpe_ctx *ctx, uint32_t on);
+gpe_status gpe_reset_timings(gpe_ctx *ctx);
+/* Synchronises, then writes up to *count entries; *count receives the number available. */
+gpe_status gpe_get_timings(gpe_ctx *ctx, gpe_timing *out, uint32_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPE_H */

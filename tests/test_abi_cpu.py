@@ -1,0 +1,66 @@
+"""CPU checks of the drop-in boundary: libgpe.so loads and exports every symbol include/gpe.h
+declares; without a GPU the library refuses to create a context (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gpe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_module_api():
+    syms = _declared_symbols()
+    for must in ("gpe_create", "gpe_destroy", "gpe_set_particles", "gpe_add_particles", "gpe_morton_resort",
+                 "gpe_grid_build", "gpe_grid_sort", "gpe_grid_update", "gpe_solve_collisions", "gpe_integrate",
+                 "gpe_step", "gpe_run", "gpe_download", "gpe_sort_pairs_u32", "gpe_inclusive_scan_u32",
+                 "gpe_get_timings", "gpe_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(gpe):
+    gpe.build()
+    lib = ctypes.CDLL(gpe._lib.LIB_PATH)
+    missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
+    assert missing == []
+    bound = {name for name, _, _ in gpe._lib.SYMBOLS}
+    assert bound == set(_declared_symbols())
+    assert gpe._lib.load().gpe_abi_version() == 1
+
+
+def test_config_defaults_are_the_reference_constants(gpe):
+    cfg = gpe._lib.GpeConfig()
+    assert gpe._lib.load().gpe_config_default(ctypes.byref(cfg)) == 0
+    assert cfg.struct_size == ctypes.sizeof(gpe._lib.GpeConfig)
+    assert (cfg.world_width, cfg.world_height) == (3048.0, 1048.0)          # state.rs:35
+    assert (cfg.gravity_x, cfg.gravity_y) == (0.0, 0.0)                      # particle_integration.wgsl:21
+    assert abs(cfg.cell_size_multiplier - 2.2) < 1e-7                        # grid.rs:20
+    assert abs(cfg.stiffness - 0.6) < 1e-7                                   # collision_solver.wgsl:2
+    assert cfg.mouse_strength == 150.0                                       # particle_integration.wgsl:22
+    assert gpe._lib.load().gpe_compute_cell_size(10.0) == 22.0               # tests/grid.rs:109
+
+
+def test_no_gpu_means_loud_failure_not_fallback(gpe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(gpe.GpeError) as e:
+        gpe.Context()
+    assert e.value.status == gpe._lib.GPE_ERR_NO_DEVICE
+
+
+def test_product_path_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "gpu-physics-engine_amd")
+    for base, _, files in os.walk(pkg):
+        if os.path.basename(base) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(base, f)).read()
+                assert "gpe_oracle" not in text and "import oracle" not in text and "orc_" not in text, f

@@ -1,0 +1,191 @@
+"""GPU (-m gpu): whole-step parity of the HIP path (through the C-ABI) against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact for every integer artefact (Morton ids, (cell,object) pairs, sorted
+order, collision-cell list) and -- because both sides evaluate the same IEEE binary32 operations in the
+same order with no FMA contraction -- bit-exact positions; the north-star tolerance for positions vs the
+reference WGSL is 1e-5 relative (driver-defined sqrt/div rounding there), asserted as the fallback bound."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+U = 0xFFFFFFFF
+REL_TOL = 1e-5
+
+
+def _assert_positions(got, want, what):
+    if np.array_equal(got, want):
+        return
+    # not bit-exact: report how far, then fail unless inside the north-star tolerance
+    denom = np.maximum(np.abs(want), 1e-30)
+    rel = np.max(np.abs(got - want) / denom)
+    nbad = int((got != want).sum())
+    assert rel <= REL_TOL, "%s: %d values differ, max rel %.3g" % (what, nbad, rel)
+    pytest.fail("%s: within 1e-5 (max rel %.3g, %d values) but NOT bit-exact vs the oracle" % (what, rel, nbad))
+
+
+def _scene(gpe, kind, n, seed):
+    if kind == "reference_density":
+        world = gpe.scenes.world_for(n)
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
+    elif kind == "dense":
+        world = gpe.scenes.world_for(n, density=1.0)
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
+    elif kind == "mixed_radii":
+        world = gpe.scenes.world_for(n, density=0.02)
+        pos, rad = gpe.scenes.mixed_radius_cloud(n, world, seed=seed)
+    else:
+        raise ValueError(kind)
+    return world, pos, rad
+
+
+@pytest.mark.parametrize("kind,n,steps", [
+    ("reference_density", 1, 3), ("reference_density", 2, 3), ("reference_density", 1000, 20),
+    ("reference_density", 20_000, 12), ("dense", 20_000, 8), ("mixed_radii", 20_000, 8),
+    ("reference_density", 200_000, 4),
+])
+def test_step_matches_oracle(gpe, oracle, kind, n, steps):
+    world, pos, rad = _scene(gpe, kind, n, seed=1000 + n)
+    max_r = float(np.abs(rad).max())
+    st = gpe.State(pos, rad, world=world)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], max_r))
+    dt = 1.0 / 60.0
+    for s in range(steps):
+        resort = (s == 0) or (s == 5)            # first frame always sorts (particle_system.rs:45)
+        st.update(dt, resort=resort)
+        sim.step(dt, resort=resort)
+        if s == 0:
+            # integer artefacts of the first step
+            assert np.array_equal(st.particles.download_home_cell_ids(), sim.home_cell_ids)
+            assert np.array_equal(st.particles.download_particle_ids(), sim.particle_ids)
+            k = sim.num_collision_cells
+            assert st.collision_system.num_collision_cells() == k
+            cid, oid = st.grid.download_cell_ids(), st.grid.download_object_ids()
+            assert np.array_equal(cid, sim.cell_ids)
+            used = sim.cell_ids != U
+            assert np.array_equal(oid[used], sim.object_ids[used])
+            assert np.array_equal(st.collision_system.download_collision_cells()[:k], sim.collision_cells[:k])
+    _assert_positions(st.positions(), sim.pos, "positions after %d steps" % steps)
+    _assert_positions(st.previous_positions(), sim.prev, "previous positions")
+    # later-step integer artefacts too (stale object ids behind UNUSED keys are not compared: SURVEY App. B.1)
+    cid = st.grid.download_cell_ids()
+    assert np.array_equal(cid, sim.cell_ids)
+    used = cid != U
+    assert np.array_equal(st.grid.download_object_ids()[used], sim.object_ids[used])
+    k = sim.num_collision_cells
+    assert st.collision_system.num_collision_cells() == k
+    assert np.array_equal(st.collision_system.download_collision_cells()[:k], sim.collision_cells[:k])
+    st.close(); sim.close()
+
+
+def test_gravity_and_mouse_match_oracle(gpe, oracle):
+    n = 5000
+    world, pos, rad = _scene(gpe, "reference_density", n, seed=77)
+    g = (0.0, -9.81)
+    st = gpe.State(pos, rad, world=world, gravity=g)
+    p = oracle.default_params(world[0], world[1], 0.5, gravity=g)
+    p.mouse_pressed, p.mouse_x, p.mouse_y = 1, world[0] * 0.4, world[1] * 0.6
+    st.particles.mouse_click_callback(True, (p.mouse_x, p.mouse_y))
+    sim = oracle.Sim(pos, rad, p)
+    for s in range(15):
+        st.update(1.0 / 60.0, resort=(s == 0))
+        sim.step(1.0 / 60.0, resort=(s == 0))
+    _assert_positions(st.positions(), sim.pos, "positions (gravity + mouse)")
+    _assert_positions(st.previous_positions(), sim.prev, "previous positions (gravity + mouse)")
+    st.close(); sim.close()
+
+
+def test_negative_phantom_cells_and_unused_alias(gpe, oracle):
+    """Particles closer than r to the x=0 / y=0 walls overlap cell -1, which aliases to coordinate 65535
+    (grid.wgsl:102); the corner cell (-1,-1) hashes to 0xFFFFFFFF == UNUSED_CELL_ID and is never a
+    collision cell (collision_cell_builder.wgsl:56).  SURVEY Appendix B.7."""
+    pos = np.array([[0.2, 0.2], [0.3, 0.25], [0.1, 5.0], [0.15, 5.2], [7.0, 0.05], [7.3, 0.1],
+                    [0.0, 0.0], [0.05, 0.02], [30.0, 30.0]], np.float32)
+    rad = np.full(len(pos), 0.5, np.float32)
+    world = (64.0, 64.0)
+    st = gpe.State(pos, rad, world=world)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    st.grid.build_cell_ids(); sim.grid_build()
+    assert np.array_equal(st.grid.download_cell_ids(), sim.cell_ids)
+    assert (sim.cell_ids.reshape(-1, 4)[:, 1:] == U).any() and (sim.cell_ids == 0x55555555).any()
+    for s in range(6):
+        st.update(1.0 / 60.0, resort=(s == 0)); sim.step(1.0 / 60.0, resort=(s == 0))
+        if s == 0:
+            k = sim.num_collision_cells
+            assert st.collision_system.num_collision_cells() == k
+            assert np.array_equal(st.collision_system.download_collision_cells()[:k], sim.collision_cells[:k])
+    _assert_positions(st.positions(), sim.pos, "positions near the origin walls")
+    st.close(); sim.close()
+
+
+def test_module_calls_compose_like_step(gpe, oracle):
+    """gpe_grid_build / gpe_grid_sort / gpe_solve_collisions / gpe_integrate one by one == gpe_step."""
+    n = 10_000
+    world, pos, rad = _scene(gpe, "dense", n, seed=5)
+    a = gpe.State(pos, rad, world=world)
+    b = gpe.State(pos, rad, world=world)
+    for s in range(4):
+        a.update(0.01, resort=(s == 0))
+        if s == 0:
+            b.particles.sort_by_cell_id(b.grid.cell_size())
+        b.grid.build_cell_ids(); b.grid.sort_map(); b.collision_system.solve_collisions()
+        b.particles.update_positions(0.01)
+    assert np.array_equal(a.positions(), b.positions())
+    assert np.array_equal(a.previous_positions(), b.previous_positions())
+    a.close(); b.close()
+
+
+def test_add_particles_matches_fresh_system(gpe, oracle):
+    """State::add_particles (state.rs:187-200): grown buffers, new max radius => new cell size."""
+    n = 3000
+    world = (200.0, 120.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=21)
+    extra_pos, extra_rad = gpe.scenes.mixed_radius_cloud(100, world, seed=22, radii=(1.0, 2.0, 3.0))
+    st = gpe.State(pos, rad, world=world)
+    st.update(1 / 60, resort=True)
+    cur, prev = st.positions(), st.previous_positions()
+    st.add_particles(extra_pos, extra_rad)
+    assert st.particles.len() == n + 100
+    assert st.particles.get_max_radius() == 3.0
+    assert st.grid.cell_size() == np.float32(3.0) * np.float32(2.2)
+    all_pos = np.concatenate([cur, extra_pos]); all_prev = np.concatenate([prev, extra_pos])
+    all_rad = np.concatenate([rad[st.particles.download_particle_ids()], extra_rad])
+    sim = oracle.Sim(all_pos, all_rad, oracle.default_params(world[0], world[1], 3.0), prev=all_prev)
+    for s in range(5):
+        st.update(1 / 60, resort=(s == 2)); sim.step(1 / 60, resort=(s == 2))
+    _assert_positions(st.positions(), sim.pos, "positions after add_particles")
+    st.close(); sim.close()
+
+
+def test_run_equals_repeated_step(gpe):
+    n = 20_000
+    world, pos, rad = _scene(gpe, "reference_density", n, seed=9)
+    a = gpe.State(pos, rad, world=world)
+    b = gpe.State(pos, rad, world=world)
+    a.run(1 / 60, 12, resort_every=5, resort_first=True)
+    for s in range(12):
+        b.update(1 / 60, resort=(s % 5 == 0))
+    assert np.array_equal(a.positions(), b.positions())
+    a.close(); b.close()
+
+
+def test_full_size_1m_properties(gpe, oracle):
+    """BASELINE config 2 (1M particles, reference world): size-independent properties + an oracle step."""
+    n = 1_000_000
+    world = gpe.scenes.REF_WORLD
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    st = gpe.State(pos, rad, world=world)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    st.update(1 / 60, resort=True); sim.step(1 / 60, resort=True)
+    ids = st.particles.download_particle_ids()
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))           # a permutation
+    home = st.particles.download_home_cell_ids()
+    assert (np.diff(home.astype(np.int64)) >= 0).all()                           # Morton-sorted
+    cid = st.grid.download_cell_ids()
+    assert (np.diff(cid.astype(np.int64)) >= 0).all()
+    assert np.array_equal(cid, sim.cell_ids)
+    k = sim.num_collision_cells
+    assert st.collision_system.num_collision_cells() == k
+    assert np.array_equal(st.collision_system.download_collision_cells()[:k], sim.collision_cells[:k])
+    _assert_positions(st.positions(), sim.pos, "1M positions after one step")
+    p = st.positions()
+    assert (p[:, 0] >= 0.5).all() and (p[:, 0] <= world[0] - 0.5).all()          # wall clamp
+    st.close(); sim.close()
