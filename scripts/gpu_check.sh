@@ -20,7 +20,7 @@ run_step() {  # name, seconds, command...
 run_step build 300 python __graft_entry__.py
 run_step smoke 300 python -c "import __graft_entry__ as g; g.smoke()"
 SMOKE=$?
-run_step pytest_gpu 1000 python -m pytest tests -m gpu -q --timeout 600 -x
+run_step pytest_gpu 1000 python -m pytest tests -m gpu -q --timeout 600
 if [ "${SKIP_BENCH:-0}" != "1" ] && [ $SMOKE -eq 0 ]; then
     run_step bench 600 python bench.py ${BENCH_ARGS:-}
     grep -h '^{' gpurun_out/bench.log > gpurun_out/bench.json || true

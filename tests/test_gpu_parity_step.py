@@ -142,12 +142,13 @@ def test_add_particles_matches_fresh_system(gpe, oracle):
     st = gpe.State(pos, rad, world=world)
     st.update(1 / 60, resort=True)
     cur, prev = st.positions(), st.previous_positions()
+    perm = st.particles.download_particle_ids()
     st.add_particles(extra_pos, extra_rad)
     assert st.particles.len() == n + 100
     assert st.particles.get_max_radius() == 3.0
     assert st.grid.cell_size() == np.float32(3.0) * np.float32(2.2)
     all_pos = np.concatenate([cur, extra_pos]); all_prev = np.concatenate([prev, extra_pos])
-    all_rad = np.concatenate([rad[st.particles.download_particle_ids()], extra_rad])
+    all_rad = np.concatenate([rad[perm], extra_rad])
     sim = oracle.Sim(all_pos, all_rad, oracle.default_params(world[0], world[1], 3.0), prev=all_prev)
     for s in range(5):
         st.update(1 / 60, resort=(s == 2)); sim.step(1 / 60, resort=(s == 2))
