@@ -1,6 +1,7 @@
 // gpe_api.hip -- the extern "C" boundary of include/gpe.h: context, buffers, step ordering,
 // downloads, profiling.  All device work goes to one in-order hipStream per context.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -318,6 +319,7 @@ gpe_status gpe_create(const gpe_config *cfg, gpe_ctx **out)
     c->cfg = local;
     c->device = dev;
     c->profiling = local.profiling != 0;
+    if (const char *e = getenv("GPE_SORT")) c->use_onesweep = strcmp(e, "safe") != 0;
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         std::string m = std::string("gpe_create: ") + hipGetErrorName(e);
@@ -338,6 +340,7 @@ gpe_status gpe_destroy(gpe_ctx *c)
     free_particle_buffers(c);
     sort_release(c);
     scan_release(c);
+    onesweep_release(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPE_OK;

@@ -157,6 +157,31 @@ struct SortWorkspace {
     uint32_t *hist4 = nullptr;                       // 4 x 256 global digit histograms
 };
 
+struct OnesweepWorkspace {
+    uint64_t *status = nullptr;      // [tiles][256] {epoch:30, flag:2, value:32}
+    uint64_t status_cap = 0;
+    uint32_t *hist4 = nullptr;       // 4 x 256 digit histograms
+    uint32_t *bases4 = nullptr;      // 4 x 256 exclusive digit bases
+    uint32_t *ctl = nullptr;         // [0..3] tile tickets per pass, [4] error word
+    uint32_t epoch = 0;
+};
+
+// Native (N-key sort + LDS cell windows) pipeline state
+struct NativeState {
+    bool eligible = false;           // every particle inside the world box, grid small enough
+    int32_t gx = 0, gy = 0;          // home cell columns / rows: cx in [0,gx), cy in [0,gy)
+    int passes = 4;                  // radix passes needed for morton(gx-1, gy-1)
+    uint32_t table_entries = 0;      // 8x8-cell block table length
+    uint2 *block_table = nullptr;    // [morton >> 6] = (start, end) in the sorted order
+    uint64_t table_cap = 0;
+    uint32_t *keys = nullptr, *ids = nullptr;       // N each: hash output / sort ping
+    uint32_t *keys_b = nullptr, *ids_b = nullptr;   // sort pong
+    uint64_t cap = 0;
+    uint32_t *tile_ctl = nullptr;    // [0] overflow count (T=32 -> T=8), [1] error bits, [2] spill count
+    uint32_t *overflow_tiles = nullptr;             // packed (ty << 16 | tx) of tiles over capacity
+    uint64_t overflow_cap = 0;
+};
+
 }  // namespace gpe
 
 struct gpe_ctx {
@@ -188,6 +213,9 @@ struct gpe_ctx {
 
     gpe::SortWorkspace sort_ws;
     gpe::ScanWorkspace scan_ws;
+    gpe::OnesweepWorkspace os_ws;
+    gpe::NativeState native;
+    bool use_onesweep = true;        // GPE_SORT=safe selects the reduce-then-scan sort
 
     // profiling
     bool profiling = false;
@@ -248,6 +276,17 @@ gpe_status scan_reserve(gpe_ctx *c, uint64_t n);
 gpe_status inclusive_scan(gpe_ctx *c, uint32_t *data, uint64_t n);
 void sort_release(gpe_ctx *c);
 void scan_release(gpe_ctx *c);
+// onesweep (k_onesweep.hip)
+gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n);
+void onesweep_release(gpe_ctx *c);
+gpe_status onesweep_zero_hist(gpe_ctx *c);
+gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
+                         uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
+                         uint32_t **out_vals);
+// native pipeline (k_native.hip)
+gpe_status native_configure(gpe_ctx *c, const float *pos_xy_host, uint64_t n_host_checked);
+void native_release(gpe_ctx *c);
+gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out);
 // collision cells + solver
 gpe_status launch_count_chunks(gpe_ctx *c, const uint32_t *cell_ids, uint64_t total, uint32_t *chunk_counts);
 gpe_status launch_build_collision_cells(gpe_ctx *c, const uint32_t *cell_ids, uint64_t total,

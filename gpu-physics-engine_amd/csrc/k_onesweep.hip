@@ -1,0 +1,307 @@
+// k_onesweep.hip -- onesweep-style LSD radix sort of (u32 key, u32 payload) pairs for gfx950.
+//
+//   1. ONE upfront pass builds the 256-bin histogram of every 8-bit digit (LDS histograms, flushed
+//      with one global atomic per bin per workgroup).  The native step fuses this into the cell-hash
+//      kernel (k_native.hip), so the keys are not even re-read.
+//   2. k_os_prepare turns the histograms into exclusive digit bases and resets the tile tickets.
+//   3. One kernel per digit: a workgroup takes a tile ticket, ranks its 4096 keys with wave64 ballots
+//      (stable), publishes its per-digit tile counts, resolves the counts of all preceding tiles by
+//      decoupled look-back over 8-byte {epoch, flag, value} status words, reorders the tile in LDS and
+//      writes each digit's run as one coalesced store.  Per pass: R 8 B + W 8 B per pair.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, form R2 "the data is the flag"):
+// a status word is ONE naturally aligned 8-byte granule written by one relaxed agent-scope atomic
+// store (sc1) and read by relaxed agent-scope atomic loads; no other memory is handed over inside a
+// launch, so no fences are needed.  Tickets come from an atomic counter, so a tile only ever waits
+// for tiles that are already resident => forward progress whatever the dispatch order.  Status
+// words carry an epoch (sort call x pass), so the array is never cleared between passes; spins are
+// bounded and report through an error word instead of hanging the GPU.
+#include "gpe_internal.h"
+
+namespace gpe {
+
+constexpr int kOsBlock = 256;
+constexpr int kOsWaves = kOsBlock / 64;
+constexpr int kOsItems = 16;
+constexpr int kOsTile = kOsBlock * kOsItems;     // 4096 keys
+constexpr int kOsWaveSpan = 64 * kOsItems;
+
+constexpr uint64_t kFlagAggregate = 1ull;        // value = this tile's count of the digit
+constexpr uint64_t kFlagPrefix = 2ull;           // value = count of the digit in tiles 0..this
+constexpr uint32_t kSpinLimit = 1u << 24;
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint64_t os_match_digit(uint32_t d, bool valid)
+{
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+// LDS histogram add for one wave-round: one atomic when the whole wave holds one digit (the common
+// case for the high digits of nearly sorted keys), else one atomic per lane.
+__device__ __forceinline__ void hist_add(uint32_t *s_hist, uint32_t d, bool valid)
+{
+    const uint64_t act = __ballot(valid);
+    if (act == 0) return;
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(valid ? d : 0xffffffffu);
+    // readfirstlane takes the first ACTIVE lane; all lanes are active here, lane 0 may be invalid
+    const bool uniform = __all(!valid || d == d0) && d0 != 0xffffffffu;
+    if (uniform) {
+        if (lane_id() == 0) atomicAdd(&s_hist[d0], (uint32_t)__popcll(act));
+    } else if (valid) {
+        atomicAdd(&s_hist[d], 1u);
+    }
+}
+
+// 1. all four digit histograms in one read of the keys: hist4[p*256 + d]
+__global__ __launch_bounds__(kOsBlock) void k_os_hist4(const uint32_t *__restrict__ keys, uint64_t n,
+                                                        uint32_t *__restrict__ hist4)
+{
+    __shared__ uint32_t s_hist[4 * 256];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s_hist[p * 256 + threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t idx = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = idx < n;
+        const uint32_t key = valid ? keys[idx] : 0u;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) hist_add(s_hist + p * 256, (key >> (8 * p)) & 255u, valid);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t v = s_hist[p * 256 + threadIdx.x];
+        if (v) atomicAdd(&hist4[p * 256 + threadIdx.x], v);
+    }
+}
+
+// 2. exclusive digit bases per pass; reset the four tile tickets and the error word.
+//    ctl: [0..3] tickets, [4] error
+__global__ __launch_bounds__(256) void k_os_prepare(const uint32_t *__restrict__ hist4,
+                                                     uint32_t *__restrict__ bases4, uint32_t *__restrict__ ctl)
+{
+    __shared__ uint32_t s_w[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t v = hist4[p * 256 + threadIdx.x];
+        bases4[p * 256 + threadIdx.x] = block256_exclusive_scan(v, s_w, nullptr);
+    }
+    if (threadIdx.x < 8) ctl[threadIdx.x] = 0;
+}
+
+__device__ __forceinline__ u64 status_pack(uint32_t epoch, uint64_t flag, uint32_t value)
+{
+    return ((u64)epoch << 34) | (flag << 32) | (u64)value;
+}
+
+// 3. one digit pass.  IOTA: the payload of input element i is i itself (first pass of a sort whose
+//    payload is the identity), saving the payload read.
+template <bool IOTA>
+__global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict__ keys_in,
+                                                       const uint32_t *__restrict__ vals_in,
+                                                       uint32_t *__restrict__ keys_out,
+                                                       uint32_t *__restrict__ vals_out, uint64_t n,
+                                                       uint32_t shift, uint32_t pass,
+                                                       const uint32_t *__restrict__ bases4, u64 *status,
+                                                       uint32_t *ctl, uint32_t epoch)
+{
+    __shared__ uint32_t s_keys[kOsTile];
+    __shared__ uint32_t s_vals[kOsTile];
+    __shared__ uint32_t s_whist[kOsWaves][256];
+    __shared__ uint32_t s_excl[256];
+    __shared__ uint32_t s_delta[256];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_tile;
+
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[pass], 1u);     // ticket: tiles start in ticket order
+#pragma unroll
+    for (int i = 0; i < kOsWaves; ++i) s_whist[i][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    const uint64_t tile_base = (uint64_t)tile * kOsTile;
+    const uint64_t wave_base = tile_base + (uint64_t)w * kOsWaveSpan;
+    const uint32_t tile_n = (uint32_t)((n - tile_base < (uint64_t)kOsTile) ? (n - tile_base) : kOsTile);
+
+    uint32_t key[kOsItems], val[kOsItems];
+    uint16_t rank[kOsItems];
+#pragma unroll
+    for (int k = 0; k < kOsItems; ++k) {
+        const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
+        const bool valid = idx < n;
+        key[k] = valid ? keys_in[idx] : 0xffffffffu;
+        if (IOTA) val[k] = (uint32_t)idx;
+        else val[k] = valid ? vals_in[idx] : 0u;
+    }
+    volatile uint32_t *wh = s_whist[w];
+#pragma unroll
+    for (int k = 0; k < kOsItems; ++k) {
+        const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (key[k] >> shift) & 255u;
+        const uint64_t m = os_match_digit(d, valid);
+        const uint32_t below = popc_below_lane(m);
+        const uint32_t pre = wh[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        rank[k] = (uint16_t)(pre + below);
+    }
+    __syncthreads();
+
+    // one thread per digit: tile count, wave offsets, publish, look back, publish prefix
+    {
+        const uint32_t d = threadIdx.x;
+        const uint32_t c0 = s_whist[0][d], c1 = s_whist[1][d], c2 = s_whist[2][d], c3 = s_whist[3][d];
+        s_whist[0][d] = 0; s_whist[1][d] = c0; s_whist[2][d] = c0 + c1; s_whist[3][d] = c0 + c1 + c2;
+        const uint32_t count = c0 + c1 + c2 + c3;
+        u64 *mine = status + (uint64_t)tile * 256 + d;
+        if (tile > 0)
+            __hip_atomic_store(mine, status_pack(epoch, kFlagAggregate, count), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t before = 0;                                   // digit d in tiles [0, tile)
+        bool failed = false;
+        for (int64_t t = (int64_t)tile - 1; t >= 0;) {
+            const u64 *p = status + (uint64_t)t * 256 + d;
+            u64 s = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t spins = 0;
+            while ((uint32_t)(s >> 34) != epoch || ((s >> 32) & 3ull) == 0ull) {
+                if (++spins > kSpinLimit) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                s = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (failed) break;
+            before += (uint32_t)s;
+            if (((s >> 32) & 3ull) == kFlagPrefix) break;
+            --t;
+        }
+        if (failed) atomicOr(&ctl[4], 1u);
+        __hip_atomic_store(mine, status_pack(epoch, kFlagPrefix, before + count), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t excl = block256_exclusive_scan(count, s_w, nullptr);
+        s_excl[d] = excl;
+        s_delta[d] = bases4[pass * 256 + d] + before - excl;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < kOsItems; ++k) {
+        const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (key[k] >> shift) & 255u;
+            const uint32_t slot = s_excl[d] + s_whist[w][d] + rank[k];
+            s_keys[slot] = key[k];
+            s_vals[slot] = val[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < tile_n; j += kOsBlock) {
+        const uint32_t kk = s_keys[j];
+        const uint32_t d = (kk >> shift) & 255u;
+        const uint32_t dst = s_delta[d] + j;
+        keys_out[dst] = kk;
+        vals_out[dst] = s_vals[j];
+    }
+}
+
+static uint64_t os_tiles(uint64_t n) { return (n + kOsTile - 1) / kOsTile; }
+
+gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n)
+{
+    OnesweepWorkspace &ws = c->os_ws;
+    const uint64_t need = os_tiles(n) * 256 + 256;
+    if (ws.status_cap < need) {
+        if (ws.status) GPE_HIP(c, hipFree(ws.status));
+        ws.status = nullptr; ws.status_cap = 0;
+        GPE_HIP(c, hipMalloc((void **)&ws.status, need * sizeof(uint64_t)));
+        GPE_HIP(c, hipMemsetAsync(ws.status, 0, need * sizeof(uint64_t), c->stream));   // epoch 0 = never
+        ws.status_cap = need;
+    }
+    if (!ws.hist4) {
+        GPE_HIP(c, hipMalloc((void **)&ws.hist4, (4 * 256 + 4 * 256 + 64) * sizeof(uint32_t)));
+        ws.bases4 = ws.hist4 + 4 * 256;
+        ws.ctl = ws.bases4 + 4 * 256;
+        GPE_HIP(c, hipMemsetAsync(ws.hist4, 0, (4 * 256 + 4 * 256 + 64) * sizeof(uint32_t), c->stream));
+    }
+    return GPE_OK;
+}
+
+void onesweep_release(gpe_ctx *c)
+{
+    OnesweepWorkspace &ws = c->os_ws;
+    if (ws.status) (void)hipFree(ws.status);
+    if (ws.hist4) (void)hipFree(ws.hist4);
+    ws = OnesweepWorkspace();
+}
+
+gpe_status onesweep_zero_hist(gpe_ctx *c)
+{
+    GPE_HIP(c, hipMemsetAsync(c->os_ws.hist4, 0, 4 * 256 * sizeof(uint32_t), c->stream));
+    return GPE_OK;
+}
+
+// Passes over digits [0, passes): (keys, vals) ping-pong with (keys_b, vals_b).  Returns through
+// *out_keys/*out_vals the buffers holding the result (the caller's when `passes` is even).
+// hist_ready: hist4 already holds the four digit histograms of `keys` (fused producer).
+// iota_vals: the payload is the identity permutation and `vals` need not be initialised.
+gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
+                         uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
+                         uint32_t **out_vals)
+{
+    if (out_keys) *out_keys = keys;
+    if (out_vals) *out_vals = vals;
+    if (n == 0) return GPE_OK;
+    if (n > 0xffffffffull) return fail(c, GPE_ERR_INVALID_ARG, "onesweep: n must be < 2^32");
+    if (passes < 1 || passes > 4) return fail(c, GPE_ERR_INVALID_ARG, "onesweep: passes must be 1..4");
+    OnesweepWorkspace &ws = c->os_ws;
+    const uint64_t tiles = os_tiles(n);
+    if (!hist_ready) {
+        Scope s(c, "sort/hist");
+        GPE_TRY(onesweep_zero_hist(c));
+        hipLaunchKernelGGL(k_os_hist4, dim3(stream_grid(n, kOsBlock)), dim3(kOsBlock), 0, c->stream, keys, n,
+                           ws.hist4);
+        GPE_HIP(c, hipGetLastError());
+    }
+    {
+        Scope s(c, "sort/prepare");
+        hipLaunchKernelGGL(k_os_prepare, dim3(1), dim3(256), 0, c->stream, ws.hist4, ws.bases4, ws.ctl);
+        GPE_HIP(c, hipGetLastError());
+    }
+    uint32_t *ka = keys, *va = vals, *kb = keys_b, *vb = vals_b;
+    for (int p = 0; p < passes; ++p) {
+        ws.epoch += 1;
+        if (ws.epoch >= (1u << 30)) {             // epoch field is 30 bits: restart from a clean array
+            GPE_HIP(c, hipMemsetAsync(ws.status, 0, ws.status_cap * sizeof(uint64_t), c->stream));
+            ws.epoch = 1;
+        }
+        Scope s(c, "sort/onesweep");
+        if (p == 0 && iota_vals)
+            hipLaunchKernelGGL(k_os_pass<true>, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb,
+                               vb, n, (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl,
+                               ws.epoch);
+        else
+            hipLaunchKernelGGL(k_os_pass<false>, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb,
+                               vb, n, (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl,
+                               ws.epoch);
+        GPE_HIP(c, hipGetLastError());
+        uint32_t *t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+    }
+    if (out_keys) *out_keys = ka;
+    if (out_vals) *out_vals = va;
+    return GPE_OK;
+}
+
+}  // namespace gpe

@@ -190,6 +190,7 @@ gpe_status sort_reserve(gpe_ctx *c, uint64_t n)
     }
     if (!ws.hist4) GPE_HIP(c, hipMalloc((void **)&ws.hist4, 4 * 256 * sizeof(uint32_t)));
     GPE_TRY(scan_reserve(c, need));
+    GPE_TRY(onesweep_reserve(c, n));
     return GPE_OK;
 }
 
@@ -234,6 +235,9 @@ gpe_status sort_scatter_pass(gpe_ctx *c, const uint32_t *ka, const uint32_t *va,
 gpe_status sort_pairs(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint64_t n)
 {
     if (n == 0) return GPE_OK;
+    if (c->use_onesweep)   // four passes: the result lands back in (keys, vals)
+        return onesweep_sort(c, keys, vals, c->sort_ws.keys_b, c->sort_ws.vals_b, n, 4, false, false, nullptr,
+                             nullptr);
     uint32_t *ka = keys, *va = vals, *kb = c->sort_ws.keys_b, *vb = c->sort_ws.vals_b;
     for (uint32_t pass = 0; pass < 4; ++pass) {
         GPE_TRY(sort_scatter_pass(c, ka, va, kb, vb, n, pass * 8u));
