@@ -243,6 +243,14 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
 {
     // state.rs:115-131
     if (flags & GPE_STEP_RESORT) GPE_TRY(do_resort(c));                          // :122-125
+    if (c->cfg.mode == GPE_MODE_NATIVE && c->native.eligible) {
+        // grid update + collision solve as N-key sort + LDS cell windows (k_native.hip); the resolved
+        // positions land in the scratch set, which then becomes the live one
+        GPE_TRY(native_collide(c, c->pos, c->pos_copy));
+        std::swap(c->pos, c->pos_copy);
+        GPE_TRY(launch_verlet(c, c->pos, c->prev, c->radius, c->n, dt));         // :130
+        return GPE_OK;
+    }
     GPE_TRY(launch_build_cell_ids(c, c->pos, c->radius, c->n, c->cell_size, c->cell_ids,
                                   c->object_ids));                               // :126 Grid::update
     GPE_TRY(do_grid_sort(c));
@@ -341,8 +349,36 @@ gpe_status gpe_destroy(gpe_ctx *c)
     sort_release(c);
     scan_release(c);
     onesweep_release(c);
+    native_release(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return GPE_OK;
+}
+
+// Device-side error words (sticky): reported at the synchronising entry points.
+static gpe_status check_device_errors(gpe_ctx *c)
+{
+    uint32_t words[2] = {0, 0};
+    if (c->native.tile_ctl)
+        GPE_HIP(c, hipMemcpyAsync(&words[0], c->native.tile_ctl + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->os_ws.ctl)
+        GPE_HIP(c, hipMemcpyAsync(&words[1], c->os_ws.ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    if (words[1]) return fail(c, GPE_ERR_HIP, "radix sort: decoupled look-back timed out");
+    if (words[0] & 2u)
+        return fail(c, GPE_ERR_UNSUPPORTED,
+                    "native collide: a region of 24x24 cells holds more particles than the LDS cell window "
+                    "takes; results of that step are unresolved there -- use GPE_MODE_COMPAT for this scene");
+    if (words[0] & 5u)
+        return fail(c, GPE_ERR_STATE, "native collide: a particle left the world box between steps");
+    return GPE_OK;
+}
+
+// (Re)derive the native pipeline's cell box after anything it depends on changed.
+static gpe_status reconfigure(gpe_ctx *c)
+{
+    if (c->cfg.mode == GPE_MODE_NATIVE && c->n > 0) return native_configure(c);
+    c->native.eligible = false;
     return GPE_OK;
 }
 
@@ -350,7 +386,7 @@ gpe_status gpe_sync(gpe_ctx *c)
 {
     if (!c) return GPE_ERR_INVALID_ARG;
     GPE_HIP(c, hipStreamSynchronize(c->stream));
-    return GPE_OK;
+    return check_device_errors(c);
 }
 
 gpe_status gpe_set_mode(gpe_ctx *c, uint32_t mode)
@@ -358,7 +394,7 @@ gpe_status gpe_set_mode(gpe_ctx *c, uint32_t mode)
     if (!c) return GPE_ERR_INVALID_ARG;
     if (mode != GPE_MODE_COMPAT && mode != GPE_MODE_NATIVE) return fail(c, GPE_ERR_INVALID_ARG, "unknown mode");
     c->cfg.mode = mode;
-    return GPE_OK;
+    return reconfigure(c);
 }
 
 // ---- particles -----------------------------------------------------------------------------------------
@@ -385,7 +421,7 @@ gpe_status gpe_set_particles(gpe_ctx *c, const float *pos_xy, const float *prev_
     c->grid_max_radius = c->max_radius;       // Grid::new (grid.rs:66-71)
     refresh_cell_size(c);
     GPE_HIP(c, hipStreamSynchronize(c->stream));   // the host arrays may be released on return
-    return GPE_OK;
+    return reconfigure(c);
 }
 
 gpe_status gpe_add_particles(gpe_ctx *c, const float *pos_xy, const float *radius, uint64_t n_add)
@@ -435,7 +471,7 @@ gpe_status gpe_add_particles(gpe_ctx *c, const float *pos_xy, const float *radiu
     c->grid_max_radius = c->max_radius;   // Grid::refresh_grid (grid.rs:266)
     refresh_cell_size(c);
     GPE_HIP(c, hipStreamSynchronize(c->stream));
-    return GPE_OK;
+    return reconfigure(c);
 }
 
 gpe_status gpe_len(const gpe_ctx *c, uint64_t *n)
@@ -466,7 +502,7 @@ gpe_status gpe_set_world(gpe_ctx *c, float w, float h)
     if (!c) return GPE_ERR_INVALID_ARG;
     c->cfg.world_width = w;
     c->cfg.world_height = h;
-    return GPE_OK;
+    return reconfigure(c);
 }
 
 gpe_status gpe_set_gravity(gpe_ctx *c, float gx, float gy)
@@ -499,7 +535,7 @@ gpe_status gpe_grid_set_max_radius(gpe_ctx *c, float r)
     if (!c) return GPE_ERR_INVALID_ARG;
     c->grid_max_radius = r;
     refresh_cell_size(c);
-    return GPE_OK;
+    return reconfigure(c);
 }
 
 gpe_status gpe_cell_size(const gpe_ctx *c, float *cs)
@@ -616,7 +652,7 @@ gpe_status gpe_download(gpe_ctx *c, gpe_array what, void *dst, uint64_t bytes)
     GPE_HIP(c, hipSetDevice(c->device));
     GPE_HIP(c, hipMemcpyAsync(dst, p, b, hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
-    return GPE_OK;
+    return check_device_errors(c);
 }
 
 // ---- primitives ---------------------------------------------------------------------------------------------

@@ -131,6 +131,26 @@ __device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t
     return base + inc - v;
 }
 
+// LDS histogram add for one wave-round: one atomic when the whole wave holds one digit (the common
+// case for the high digits of nearly sorted keys), else one atomic per lane.
+__device__ __forceinline__ void hist_add(uint32_t *s_hist, uint32_t d, bool valid)
+{
+    // Peel up to three distinct digit values off the wave (one atomic each: the high digits of
+    // nearly sorted keys hold 1-3 values per wave and per-lane atomics on one word serialise),
+    // then fall back to one atomic per remaining lane (random low digits: few conflicts).
+    uint64_t rem = __ballot(valid);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        if (rem == 0) return;                                  // wave-uniform
+        const int first = __builtin_ctzll(rem);
+        const uint32_t d0 = __shfl(d, first, 64);
+        const uint64_t same = __ballot(valid && d == d0) & rem;
+        if (lane_id() == first) atomicAdd(&s_hist[d0], (uint32_t)__popcll(same));
+        rem &= ~same;
+    }
+    if ((rem >> lane_id()) & 1ull) atomicAdd(&s_hist[d], 1u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side context
 // ------------------------------------------------------------------------------------------------
@@ -284,7 +304,8 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
                          uint32_t **out_vals);
 // native pipeline (k_native.hip)
-gpe_status native_configure(gpe_ctx *c, const float *pos_xy_host, uint64_t n_host_checked);
+gpe_status native_configure(gpe_ctx *c);
+gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids);
 void native_release(gpe_ctx *c);
 gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out);
 // collision cells + solver

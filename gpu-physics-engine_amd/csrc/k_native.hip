@@ -1,0 +1,562 @@
+// k_native.hip -- the MI355X-native collision pipeline (GPE_MODE_NATIVE).
+//
+// The reference sorts 4N (cell, object) pairs every step and resolves collisions cell by cell through
+// global memory in four colour launches (~520 B/particle/step).  Here:
+//
+//   hash     key[i] = morton(home cell of particle i)         + the four radix histograms (fused)
+//   sort     onesweep over N (key, id) pairs                  (k_onesweep.hip)
+//   table    (start,end) of every 8x8-cell Morton block in the sorted order
+//   collide  one workgroup per 32x32-cell tile: stage the tile plus an 8-cell halo in LDS
+//            (positions, radii, ids gathered through the sorted ids), rebuild the reference's
+//            per-cell member lists (home + phantom cells, members in ascending object index) in LDS,
+//            run ALL FOUR colour passes there, write back the tile's own particles.
+//
+// Exactness: cell membership is frozen from the step-start positions
+// (grid.wgsl:39-97), pairs of a cell run sequentially in ascending object index on live positions
+// (collision_solver.wgsl:66-118), colours run 1..4.  A colour-k cell is exact when every cell that
+// shares a particle with it was exact in colours < k; with the tile's own particles needing cells
+// within +-1, the cells needed at colour k lie within +-(5-k) of the tile and their members' home
+// cells within +-5 <= halo 8.  Halo cells are recomputed redundantly by the neighbouring tiles (same
+// inputs, same operation order => same bits), so no inter-tile communication and no global colour
+// barrier is needed.  Positions are double-buffered (read pos_in, write pos_out) because neighbours
+// read a tile's step-start positions while it writes its results.
+#include "gpe_internal.h"
+
+namespace gpe {
+
+constexpr int kNatThreads = 256;
+constexpr int kHalo = 8;                       // cells = one 8x8 Morton block
+constexpr uint32_t kErrOutOfBox = 1u;          // a particle outside the configured cell box
+constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS capacity (no result!)
+constexpr uint32_t kErrRegion = 4u;            // internal: particle outside its staged region
+
+// ---------------------------------------------------------------------------------------------------
+// hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
+// (home_cell_ids.wgsl:24-31 computes the same key; the particle id is implicit in the first pass.)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNatThreads) void k_native_hash(const float2 *__restrict__ pos, uint64_t n,
+                                                              float cell_size, int32_t gx, int32_t gy,
+                                                              uint32_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ hist4,
+                                                              uint32_t *__restrict__ tile_ctl)
+{
+    __shared__ uint32_t s_hist[4 * 256];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s_hist[p * 256 + threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n + stride - 1) / stride;
+    bool oob = false;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = i < n;
+        uint32_t key = 0;
+        if (valid) {
+            const float2 p = pos[i];
+            const int32_t cx = cell_coord(p.x, cell_size), cy = cell_coord(p.y, cell_size);
+            oob |= (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy);
+            key = morton_encode(cx, cy);
+            keys[i] = key;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) hist_add(s_hist + p * 256, (key >> (8 * p)) & 255u, valid);
+    }
+    if (oob) atomicOr(&tile_ctl[1], kErrOutOfBox);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t v = s_hist[p * 256 + threadIdx.x];
+        if (v) atomicAdd(&hist4[p * 256 + threadIdx.x], v);
+    }
+}
+
+// every particle inside the cell box?  (configuration-time check, not on the step path)
+__global__ __launch_bounds__(kNatThreads) void k_native_check_box(const float2 *__restrict__ pos, uint64_t n,
+                                                                   float cell_size, int32_t gx, int32_t gy,
+                                                                   uint32_t *__restrict__ flag)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool oob = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float2 p = pos[i];
+        const int32_t cx = cell_coord(p.x, cell_size), cy = cell_coord(p.y, cell_size);
+        oob |= (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy);
+    }
+    if (oob) atomicOr(flag, kErrOutOfBox);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// table: block b = key >> 6 (an aligned 8x8-cell block is contiguous in Morton order).
+// table[b] = (first, one-past-last) position of the block's particles; empty blocks stay (0,0).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNatThreads) void k_native_block_table(const uint32_t *__restrict__ sorted_keys,
+                                                                     uint64_t n, uint2 *__restrict__ table,
+                                                                     uint32_t entries)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t b = sorted_keys[i] >> 6;
+        if (b >= entries) continue;
+        const bool first = (i == 0) || ((sorted_keys[i - 1] >> 6) != b);
+        const bool last = (i + 1 == n) || ((sorted_keys[i + 1] >> 6) != b);
+        if (first) table[b].x = (uint32_t)i;
+        if (last) table[b].y = (uint32_t)(i + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// collide
+// ---------------------------------------------------------------------------------------------------
+struct CollideArgs {
+    const float2 *pos_in;
+    const float *radius;
+    float2 *pos_out;
+    const uint32_t *sorted_ids;
+    const uint2 *table;
+    uint32_t entries;
+    float cell_size;
+    float stiffness;
+    int32_t gx, gy;              // cell box
+    int32_t tiles_x, tiles_y;    // tile grid of THIS kernel's tile size
+    uint32_t *tile_ctl;          // [0] overflow count, [1] error bits
+    uint32_t *overflow;          // packed (ty << 16 | tx) of over-capacity parent tiles
+    uint32_t overflow_cap;
+};
+
+template <int T, int CAP>
+struct TileLds {
+    static constexpr int RW = T + 2 * kHalo;
+    static constexpr int NCELL = RW * RW;
+    static constexpr int NB = RW / 8;
+    static constexpr int NBLK = NB * NB;
+    static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
+    float px[CAP], py[CAP], rad[CAP];
+    uint32_t id[CAP];
+    uint16_t home[CAP];        // local index of the home cell
+    uint16_t mcode[CAP];       // phantom cells: count in bits 12-13, 4-bit neighbour codes in bits 0-11
+    uint32_t cnt[NCELL];       // members per cell (then: fill cursor counting down to 0)
+    uint16_t cstart[NCELL + 2];
+    uint16_t mem[4 * CAP];     // member lists (local particle slots)
+    uint16_t list[NCELL];      // active cells, four colour segments of NCELL/4
+    uint32_t lcnt[4];
+    uint32_t bstart[NBLK];
+    uint32_t boff[NBLK + 1];
+    uint32_t s_w[4];
+    uint32_t misc[4];
+};
+
+// The reference's pair resolution (collision_solver.wgsl:85-111), on LDS-resident positions.
+template <class L>
+__device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint32_t e, const float stiffness)
+{
+    for (uint32_t ia = b; ia + 1 < e; ++ia) {                         // :68
+        const uint32_t a = S.mem[ia];
+        float p1x = S.px[a], p1y = S.py[a];
+        const float r1 = S.rad[a];
+        bool dirty = false;
+        for (uint32_t ib = ia + 1; ib < e; ++ib) {                    // :77
+            const uint32_t bb = S.mem[ib];
+            const float p2x = S.px[bb], p2y = S.py[bb];               // :86 live position
+            const float r2 = S.rad[bb];
+            const float vx = p1x - p2x, vy = p1y - p2y;               // :91
+            const float distance = sqrtf(vx * vx + vy * vy);          // :93
+            const float radius_sum = r1 + r2;                         // :61
+            if (radius_sum * radius_sum > distance * distance && distance > 0.0001f) {   // :95
+                const float depth = radius_sum - distance;            // :97
+                const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
+                const float cy = ((vy / distance) * depth) * stiffness;
+                const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;       // :103-104
+                const float w1 = inv1 / (inv1 + inv2);                // :107
+                const float w2 = inv2 / (inv1 + inv2);                // :108
+                p1x = p1x + cx * w1;                                  // :110
+                p1y = p1y + cy * w1;
+                S.px[bb] = p2x - cx * w2;                             // :111
+                S.py[bb] = p2y - cy * w2;
+                dirty = true;
+            }
+        }
+        if (dirty) { S.px[a] = p1x; S.py[a] = p1y; }
+    }
+}
+
+// One tile: returns false when the region exceeds the LDS capacity (nothing written).
+template <int T, int CAP>
+__device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int tx, const int ty)
+{
+    using L = TileLds<T, CAP>;
+    constexpr int RW = L::RW, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER;
+    const int tid = (int)threadIdx.x;
+    const int ox = tx * T - kHalo, oy = ty * T - kHalo;                // region origin (cells)
+
+    // ---- P0: clear, look the region's blocks up ---------------------------------------------------
+    for (int i = tid; i < NCELL; i += kNatThreads) S.cnt[i] = 0;
+    if (tid < 4) S.lcnt[tid] = 0;
+    if (tid < NBLK) {
+        const int bi = tid % NB, bj = tid / NB;
+        const int bx = (ox >> 3) + bi, by = (oy >> 3) + bj;           // ox, oy are multiples of 8
+        uint32_t start = 0, count = 0;
+        if (bx >= 0 && by >= 0 && bx * 8 < A.gx && by * 8 < A.gy) {
+            const uint32_t mb = morton_encode(bx, by);
+            if (mb < A.entries) {
+                const uint2 se = A.table[mb];
+                start = se.x;
+                count = se.y - se.x;
+            }
+        }
+        S.bstart[tid] = start;
+        S.boff[tid] = count;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0, owned = 0;
+        for (int b = 0; b < NBLK; ++b) {
+            const uint32_t cnt = S.boff[b];
+            const int bi = b % NB, bj = b / NB;
+            if (bi >= 1 && bi < NB - 1 && bj >= 1 && bj < NB - 1) owned += cnt;
+            S.boff[b] = run;
+            run += cnt;
+        }
+        S.boff[NBLK] = run;
+        S.misc[0] = run;
+        S.misc[1] = owned;
+    }
+    __syncthreads();
+    const uint32_t P = S.misc[0];
+    if (S.misc[1] == 0) return true;                                   // nothing of its own to write
+    if (P > (uint32_t)CAP) return false;
+
+    // ---- P1: gather the region's particles, count cell memberships -------------------------------
+    for (uint32_t s = tid; s < P; s += kNatThreads) {
+        int lo = 0, hi = NBLK;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (S.boff[mid] <= s) lo = mid; else hi = mid;
+        }
+        const uint32_t j = S.bstart[lo] + (s - S.boff[lo]);
+        const uint32_t id = A.sorted_ids[j];
+        const float2 p = A.pos_in[id];
+        const float r = A.radius[id];
+        const int32_t cx = cell_coord(p.x, A.cell_size), cy = cell_coord(p.y, A.cell_size);
+        int lx = cx - ox, ly = cy - oy;
+        if (lx < 0 || lx >= RW || ly < 0 || ly >= RW) {                // cannot happen with a consistent table
+            atomicOr(&A.tile_ctl[1], kErrRegion);
+            lx = min(max(lx, 0), RW - 1);
+            ly = min(max(ly, 0), RW - 1);
+        }
+        S.px[s] = p.x; S.py[s] = p.y; S.rad[s] = r; S.id[s] = id;
+        const int home = ly * RW + lx;
+        S.home[s] = (uint16_t)home;
+        atomicAdd(&S.cnt[home], 1u);
+        // phantom cells in the reference's scan order (grid.wgsl:68-90), at most three kept
+        const float sq = r * r;
+        uint32_t code = 0, pc = 0;
+#pragma unroll
+        for (int y = -1; y <= 1; ++y) {
+#pragma unroll
+            for (int x = -1; x <= 1; ++x) {
+                if (x == 0 && y == 0) continue;
+                if (is_obj_in_cell(p.x, p.y, sq, cx + x, cy + y, A.cell_size)) {
+                    if (pc < 3) {
+                        code |= (uint32_t)((y + 1) * 3 + (x + 1)) << (4 * pc);
+                        const int nlx = lx + x, nly = ly + y;
+                        if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) atomicAdd(&S.cnt[nly * RW + nlx], 1u);
+                    }
+                    ++pc;
+                }
+            }
+        }
+        S.mcode[s] = (uint16_t)(code | ((pc < 3 ? pc : 3u) << 12));
+    }
+    __syncthreads();
+
+    // ---- P2: exclusive scan of the per-cell counts -> list starts ----------------------------------
+    {
+        const int c0 = tid * PER;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (c0 + k < NCELL) sum += S.cnt[c0 + k];
+        uint32_t total = 0;
+        uint32_t run = block256_exclusive_scan(sum, S.s_w, &total);
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (c0 + k < NCELL) { S.cstart[c0 + k] = (uint16_t)run; run += S.cnt[c0 + k]; }
+        if (tid == 0) S.cstart[NCELL] = (uint16_t)total;
+    }
+    __syncthreads();
+
+    // ---- P3: fill the member lists (order fixed later by the per-cell sort) --------------------------
+    for (uint32_t s = tid; s < P; s += kNatThreads) {
+        const int home = S.home[s];
+        uint32_t k = atomicSub(&S.cnt[home], 1u) - 1u;
+        S.mem[S.cstart[home] + k] = (uint16_t)s;
+        const uint32_t code = S.mcode[s];
+        const uint32_t pc = code >> 12;
+        const int lx = home % RW, ly = home / RW;
+        for (uint32_t q = 0; q < pc; ++q) {
+            const int nb = (int)((code >> (4 * q)) & 15u);
+            const int nlx = lx + (nb % 3) - 1, nly = ly + (nb / 3) - 1;
+            if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) {
+                const int lc = nly * RW + nlx;
+                k = atomicSub(&S.cnt[lc], 1u) - 1u;
+                S.mem[S.cstart[lc] + k] = (uint16_t)s;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P4: active cells per colour; members into ascending object index ---------------------------
+    for (int lc = tid; lc < NCELL; lc += kNatThreads) {
+        const uint32_t b = S.cstart[lc], e = S.cstart[lc + 1];
+        if (e - b < 2) continue;
+        const int lx = lc % RW, ly = lc / RW;
+        const int gxx = ox + lx, gyy = oy + ly;
+        // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
+        // (collision_cell_builder.wgsl:56)
+        if (((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF)) continue;
+        const int k = (gxx & 1) + 2 * (gyy & 1);                       // colour - 1 (collision_solver.wgsl:55-58)
+        const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
+        const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
+        if (max(ex, ey) > 4 - k) continue;                             // outside the colour's exactness zone
+        for (uint32_t i = b + 1; i < e; ++i) {                         // insertion sort by object index
+            const uint16_t x = S.mem[i];
+            const uint32_t kx = S.id[x];
+            uint32_t j = i;
+            while (j > b && S.id[S.mem[j - 1]] > kx) { S.mem[j] = S.mem[j - 1]; --j; }
+            S.mem[j] = x;
+        }
+        const uint32_t idx = atomicAdd(&S.lcnt[k], 1u);
+        S.list[k * (NCELL / 4) + idx] = (uint16_t)lc;
+    }
+    __syncthreads();
+
+    // ---- P5: the four colour passes (collision_solver.rs:224), one lane per collision cell ----------
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t nk = S.lcnt[k];
+        for (uint32_t i = tid; i < nk; i += kNatThreads) {
+            const int lc = S.list[k * (NCELL / 4) + i];
+            resolve_cell(S, S.cstart[lc], S.cstart[lc + 1], A.stiffness);
+        }
+        __syncthreads();
+    }
+
+    // ---- P6: write the tile's own particles back ------------------------------------------------------
+    for (uint32_t s = tid; s < P; s += kNatThreads) {
+        const int home = S.home[s];
+        const int lx = home % RW, ly = home / RW;
+        if (lx >= kHalo && lx < kHalo + T && ly >= kHalo && ly < kHalo + T)
+            A.pos_out[S.id[s]] = make_float2(S.px[s], S.py[s]);
+    }
+    __syncthreads();
+    return true;
+}
+
+// Dense launch: one workgroup per tile, tiles dealt so that each XCD (blockIdx % 8) works through a
+// contiguous run of tile rows (neighbouring tiles share halo particles in that XCD's L2).
+template <int T, int CAP>
+__global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
+{
+    __shared__ TileLds<T, CAP> S;
+    const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
+    const uint32_t per_xcd = (total + 7u) / 8u;
+    const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
+    const int tx = (int)(t % (uint32_t)A.tiles_x), ty = (int)(t / (uint32_t)A.tiles_x);
+    if (!process_tile<T, CAP>(S, A, tx, ty)) {
+        if (threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(&A.tile_ctl[0], 1u);
+            if (slot < A.overflow_cap) A.overflow[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+            else atomicOr(&A.tile_ctl[1], kErrTileOverflow);
+        }
+    }
+}
+
+// Over-capacity parents of size TP are redone as (TP/T)^2 sub-tiles of size T by a fixed grid.
+template <int T, int CAP, int TP>
+__global__ __launch_bounds__(kNatThreads) void k_collide_sublist(CollideArgs A)
+{
+    __shared__ TileLds<T, CAP> S;
+    constexpr int R = TP / T;
+    uint32_t count = A.tile_ctl[0];
+    if (count > A.overflow_cap) count = A.overflow_cap;
+    const uint32_t work = count * (uint32_t)(R * R);
+    for (uint32_t i = blockIdx.x; i < work; i += gridDim.x) {
+        const uint32_t parent = A.overflow[i / (R * R)];
+        const int sub = (int)(i % (R * R));
+        const int tx = (int)(parent & 0xFFFFu) * R + sub % R, ty = (int)(parent >> 16) * R + sub / R;
+        if (!process_tile<T, CAP>(S, A, tx, ty)) {
+            // no smaller tile: flag loudly (gpe_sync/gpe_download report it) and pass the tile's own
+            // particles through unresolved so that the state stays finite
+            if (threadIdx.x == 0) atomicOr(&A.tile_ctl[1], kErrTileOverflow);
+            using L = TileLds<T, CAP>;
+            for (int b = threadIdx.x; b < L::NBLK; b += kNatThreads) {
+                const int bi = b % L::NB, bj = b / L::NB;
+                if (bi < 1 || bi >= L::NB - 1 || bj < 1 || bj >= L::NB - 1) continue;
+                const uint32_t n_b = S.boff[b + 1] - S.boff[b];
+                for (uint32_t q = 0; q < n_b; ++q) {
+                    const uint32_t id = A.sorted_ids[S.bstart[b] + q];
+                    A.pos_out[id] = A.pos_in[id];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+constexpr int kTileMain = 32, kCapMain = 1536;
+constexpr int kTileSub = 8, kCapSub = 2048;
+
+static uint32_t host_split(uint32_t n)
+{
+    uint32_t x = n & 0x0000FFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+void native_release(gpe_ctx *c)
+{
+    NativeState &N = c->native;
+    if (N.block_table) (void)hipFree(N.block_table);
+    if (N.keys) (void)hipFree(N.keys);
+    if (N.ids) (void)hipFree(N.ids);
+    if (N.keys_b) (void)hipFree(N.keys_b);
+    if (N.ids_b) (void)hipFree(N.ids_b);
+    if (N.tile_ctl) (void)hipFree(N.tile_ctl);
+    if (N.overflow_tiles) (void)hipFree(N.overflow_tiles);
+    N = NativeState();
+}
+
+// (Re)derive the cell box from the world and the cell size, size the workspaces, and check on the
+// device that every particle lies inside the box.  Called from the configuration entry points
+// (set/add particles, set world, set max radius) -- never on the step path; synchronises.
+gpe_status native_configure(gpe_ctx *c)
+{
+    NativeState &N = c->native;
+    N.eligible = false;
+    if (c->n == 0 || !(c->cell_size > 0.0f)) return GPE_OK;
+    // largest home coordinate a clamped particle can take: floor(world / cell_size)
+    // (K12 clamps to [r, world - r], particle_integration.wgsl:70-71)
+    const float fx = floorf(c->cfg.world_width / c->cell_size), fy = floorf(c->cfg.world_height / c->cell_size);
+    if (!(fx >= 0.0f) || !(fy >= 0.0f) || fx > 65000.0f || fy > 65000.0f) return GPE_OK;   // 16-bit cell coords
+    N.gx = (int32_t)fx + 1;
+    N.gy = (int32_t)fy + 1;
+    const uint32_t max_key = host_split((uint32_t)(N.gx - 1)) | (host_split((uint32_t)(N.gy - 1)) << 1);
+    int bits = 0;
+    while (bits < 32 && (max_key >> bits) != 0) ++bits;
+    N.passes = (bits + 7) / 8;
+    if (N.passes < 1) N.passes = 1;
+    N.table_entries = (max_key >> 6) + 1;
+    if (N.table_entries > (1u << 27)) return GPE_OK;                   // > 1 GiB of table: stay on compat
+    if (N.table_cap < N.table_entries) {
+        if (N.block_table) GPE_HIP(c, hipFree(N.block_table));
+        N.block_table = nullptr; N.table_cap = 0;
+        GPE_HIP(c, hipMalloc((void **)&N.block_table, (size_t)N.table_entries * sizeof(uint2)));
+        N.table_cap = N.table_entries;
+    }
+    if (N.cap < c->cap) {
+        uint32_t **bufs[4] = {&N.keys, &N.ids, &N.keys_b, &N.ids_b};
+        for (uint32_t **b : bufs) {
+            if (*b) GPE_HIP(c, hipFree(*b));
+            *b = nullptr;
+            GPE_HIP(c, hipMalloc((void **)b, (c->cap + 16) * sizeof(uint32_t)));
+        }
+        N.cap = c->cap;
+    }
+    const uint64_t tiles = (uint64_t)((N.gx + kTileMain - 1) / kTileMain) * ((N.gy + kTileMain - 1) / kTileMain);
+    if (N.overflow_cap < tiles) {
+        if (N.overflow_tiles) GPE_HIP(c, hipFree(N.overflow_tiles));
+        N.overflow_tiles = nullptr; N.overflow_cap = 0;
+        GPE_HIP(c, hipMalloc((void **)&N.overflow_tiles, (tiles + 16) * sizeof(uint32_t)));
+        N.overflow_cap = tiles;
+    }
+    if (!N.tile_ctl) GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, 64));
+    GPE_TRY(onesweep_reserve(c, c->cap));
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
+    hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kNatThreads), 0, c->stream, c->pos, c->n,
+                       c->cell_size, N.gx, N.gy, N.tile_ctl + 1);
+    GPE_HIP(c, hipGetLastError());
+    uint32_t flag = 1;
+    GPE_HIP(c, hipMemcpyAsync(&flag, N.tile_ctl + 1, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));         // the check's verdict is not a step error
+    N.eligible = (flag == 0);
+    return GPE_OK;
+}
+
+// hash -> sort -> block table.  *sorted_ids receives the particle ids in Morton order of their home cell.
+gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
+{
+    NativeState &N = c->native;
+    const uint64_t n = c->n;
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 4, c->stream));          // overflow count; error bits stay sticky
+    GPE_HIP(c, hipMemsetAsync(N.block_table, 0, (size_t)N.table_entries * sizeof(uint2), c->stream));
+    GPE_TRY(onesweep_zero_hist(c));
+    {
+        Scope s(c, "native/hash");
+        hipLaunchKernelGGL(k_native_hash, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, c->pos, n,
+                           c->cell_size, N.gx, N.gy, N.keys, c->os_ws.hist4, N.tile_ctl);
+        GPE_HIP(c, hipGetLastError());
+    }
+    uint32_t *sk = nullptr, *sv = nullptr;
+    {
+        Scope s(c, "native/sort");
+        GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv));
+    }
+    {
+        Scope s(c, "native/table");
+        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, sk, n,
+                           N.block_table, N.table_entries);
+        GPE_HIP(c, hipGetLastError());
+    }
+    *sorted_ids = sv;
+    return GPE_OK;
+}
+
+// pos_in (step-start positions) -> pos_out (after the four colour passes), every particle written.
+gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
+{
+    NativeState &N = c->native;
+    uint32_t *sorted_ids = nullptr;
+    GPE_TRY(native_prepare_step(c, &sorted_ids));
+    CollideArgs A;
+    A.pos_in = pos_in;
+    A.radius = c->radius;
+    A.pos_out = pos_out;
+    A.sorted_ids = sorted_ids;
+    A.table = N.block_table;
+    A.entries = N.table_entries;
+    A.cell_size = c->cell_size;
+    A.stiffness = c->cfg.stiffness;
+    A.gx = N.gx;
+    A.gy = N.gy;
+    A.tile_ctl = N.tile_ctl;
+    A.overflow = N.overflow_tiles;
+    A.overflow_cap = (uint32_t)N.overflow_cap;
+    {
+        Scope s(c, "native/collide");
+        A.tiles_x = (N.gx + kTileMain - 1) / kTileMain;
+        A.tiles_y = (N.gy + kTileMain - 1) / kTileMain;
+        const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
+        const uint32_t grid = ((total + 7u) / 8u) * 8u;
+        hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        GPE_HIP(c, hipGetLastError());
+    }
+    {
+        Scope s(c, "native/collide-dense-regions");
+        A.tiles_x = (N.gx + kTileSub - 1) / kTileSub;
+        A.tiles_y = (N.gy + kTileSub - 1) / kTileSub;
+        hipLaunchKernelGGL((k_collide_sublist<kTileSub, kCapSub, kTileMain>), dim3(512), dim3(kNatThreads), 0,
+                           c->stream, A);
+        GPE_HIP(c, hipGetLastError());
+    }
+    return GPE_OK;
+}
+
+}  // namespace gpe

@@ -35,6 +35,9 @@ typedef unsigned long long u64;
 __device__ __forceinline__ uint64_t os_match_digit(uint32_t d, bool valid)
 {
     uint64_t m = __ballot(valid);
+    // whole wave on one digit (the usual case for the high digits of nearly sorted keys)
+    const uint32_t d0 = __shfl(d, m ? __builtin_ctzll(m) : 0, 64);
+    if (__ballot(valid && d != d0) == 0) return m;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const bool bit = (d >> b) & 1u;
@@ -42,22 +45,6 @@ __device__ __forceinline__ uint64_t os_match_digit(uint32_t d, bool valid)
         m &= bit ? bal : ~bal;
     }
     return m;
-}
-
-// LDS histogram add for one wave-round: one atomic when the whole wave holds one digit (the common
-// case for the high digits of nearly sorted keys), else one atomic per lane.
-__device__ __forceinline__ void hist_add(uint32_t *s_hist, uint32_t d, bool valid)
-{
-    const uint64_t act = __ballot(valid);
-    if (act == 0) return;
-    const uint32_t d0 = __builtin_amdgcn_readfirstlane(valid ? d : 0xffffffffu);
-    // readfirstlane takes the first ACTIVE lane; all lanes are active here, lane 0 may be invalid
-    const bool uniform = __all(!valid || d == d0) && d0 != 0xffffffffu;
-    if (uniform) {
-        if (lane_id() == 0) atomicAdd(&s_hist[d0], (uint32_t)__popcll(act));
-    } else if (valid) {
-        atomicAdd(&s_hist[d], 1u);
-    }
 }
 
 // 1. all four digit histograms in one read of the keys: hist4[p*256 + d]

@@ -1,0 +1,170 @@
+"""GPU (-m gpu): the MI355X-native pipeline (GPE_MODE_NATIVE: N-key onesweep sort + LDS-staged cell windows,
+all four colour passes fused) against the CPU oracle and against the compat pipeline, through the C-ABI.
+Bar: positions bit-exact (same IEEE binary32 operation sequence per particle pair);
+1e-5 relative is the north-star bound vs the reference WGSL and the reported fallback here."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+
+
+def _assert_positions(got, want, what):
+    if np.array_equal(got, want):
+        return
+    denom = np.maximum(np.abs(want), 1e-30)
+    rel = np.max(np.abs(got - want) / denom)
+    nbad = int((got != want).any(axis=-1).sum()) if got.ndim == 2 else int((got != want).sum())
+    assert rel <= REL_TOL, "%s: %d particles differ, max rel %.3g" % (what, nbad, rel)
+    pytest.fail("%s: within 1e-5 (max rel %.3g, %d particles) but NOT bit-exact" % (what, rel, nbad))
+
+
+def _native(gpe, pos, rad, world, **kw):
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE, **kw)
+    return st
+
+
+@pytest.mark.parametrize("kind,n,steps,density", [
+    ("uniform", 1, 3, None), ("uniform", 2, 3, None), ("uniform", 500, 10, None),
+    ("uniform", 20_000, 12, None), ("uniform", 200_000, 6, None),
+    ("uniform", 30_000, 6, 1.0),          # dense: most cells are collision cells
+    ("uniform", 60_000, 4, 2.0),          # 32x32-cell regions over LDS capacity -> 8x8 sub-tiles
+    ("mixed", 20_000, 8, 0.02),           # radii 0.5..3: phantom cells of big particles
+])
+def test_native_step_matches_oracle(gpe, oracle, kind, n, steps, density):
+    if kind == "mixed":
+        world = gpe.scenes.world_for(n, density=density)
+        pos, rad = gpe.scenes.mixed_radius_cloud(n, world, seed=n)
+    else:
+        world = gpe.scenes.world_for(n) if density is None else gpe.scenes.world_for(n, density=density)
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=2000 + n)
+    st = _native(gpe, pos, rad, world)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], float(np.abs(rad).max())))
+    for s in range(steps):
+        resort = s in (0, 4)
+        st.update(1 / 60, resort=resort)
+        sim.step(1 / 60, resort=resort)
+        if s == 0:
+            _assert_positions(st.positions(), sim.pos, "positions after the first step")
+    _assert_positions(st.positions(), sim.pos, "positions after %d steps" % steps)
+    _assert_positions(st.previous_positions(), sim.prev, "previous positions")
+    assert np.array_equal(st.particles.download_particle_ids(), sim.particle_ids)
+    st.ctx.sync()
+    st.close(); sim.close()
+
+
+def test_native_equals_compat_1m(gpe):
+    """BASELINE config 2 size: native and compat pipelines agree bit for bit over 12 steps."""
+    n = 1_000_000
+    world = gpe.scenes.REF_WORLD
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    a = _native(gpe, pos, rad, world)
+    b = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
+    a.run(1 / 60, 12, resort_every=5, resort_first=True)
+    b.run(1 / 60, 12, resort_every=5, resort_first=True)
+    assert np.array_equal(a.positions(), b.positions())
+    assert np.array_equal(a.previous_positions(), b.previous_positions())
+    a.ctx.sync()
+    a.close(); b.close()
+
+
+def test_native_gravity_mouse_match_oracle(gpe, oracle):
+    n = 8000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=31)
+    g = (0.0, -9.81)
+    st = _native(gpe, pos, rad, world, gravity=g)
+    p = oracle.default_params(world[0], world[1], 0.5, gravity=g)
+    p.mouse_pressed, p.mouse_x, p.mouse_y = 1, world[0] * 0.3, world[1] * 0.7
+    st.particles.mouse_click_callback(True, (p.mouse_x, p.mouse_y))
+    sim = oracle.Sim(pos, rad, p)
+    for s in range(40):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+    _assert_positions(st.positions(), sim.pos, "positions (gravity + mouse, 40 steps)")
+    st.close(); sim.close()
+
+
+def test_native_walls_and_unused_alias(gpe, oracle):
+    """Phantom cells at coordinate -1 (x < r or y < r) and the (-1,-1) cell that aliases UNUSED_CELL_ID."""
+    rng = np.random.default_rng(4)
+    world = (40.0, 40.0)
+    edge = np.concatenate([
+        np.stack([rng.random(300, dtype=np.float32) * 0.6, rng.random(300, dtype=np.float32) * 40], 1),
+        np.stack([rng.random(300, dtype=np.float32) * 40, rng.random(300, dtype=np.float32) * 0.6], 1),
+        rng.random((200, 2), dtype=np.float32) * 0.8,
+        np.stack([40 - rng.random(300, dtype=np.float32) * 0.6, rng.random(300, dtype=np.float32) * 40], 1),
+        np.stack([rng.random(300, dtype=np.float32) * 40, 40 - rng.random(300, dtype=np.float32) * 0.6], 1),
+        rng.random((600, 2), dtype=np.float32) * 40,
+    ]).astype(np.float32)
+    rad = np.full(len(edge), 0.5, np.float32)
+    st = _native(gpe, edge, rad, world)
+    sim = oracle.Sim(edge, rad, oracle.default_params(world[0], world[1], 0.5))
+    for s in range(8):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        if s == 0:
+            _assert_positions(st.positions(), sim.pos, "first step (before any wall clamp)")
+    _assert_positions(st.positions(), sim.pos, "positions along the walls")
+    st.close(); sim.close()
+
+
+def test_native_coincident_particles(gpe, oracle, golden):
+    """tests/grid.rs:229-263 scene (546 particles at one point, radius 10) through the native path."""
+    g = golden["grid_case_2"]
+    n = g["num_particles"]
+    pos = np.tile(np.array(g["position"], np.float32), (n, 1))
+    pos[::7] += np.float32(0.37)          # some distinct positions so that pairs do get resolved
+    rad = np.full(n, g["radius"], np.float32)
+    world = (1920.0, 1080.0)
+    st = _native(gpe, pos, rad, world)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], g["max_radius"]))
+    for s in range(3):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+    _assert_positions(st.positions(), sim.pos, "coincident pile")
+    st.close(); sim.close()
+
+
+def test_native_out_of_box_scene_uses_compat_kernels(gpe, oracle):
+    """Particles outside [0,W]x[0,H] (negative cells wrap to 65535, grid.wgsl:102) are outside the native
+    cell box: the context runs the compat kernels instead -- same bits, no error."""
+    n = 2000
+    world = (100.0, 80.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=3)
+    pos[:50, 0] -= 30.0
+    pos[50:100, 1] += 70.0
+    st = _native(gpe, pos, rad, world)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    for s in range(4):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+    _assert_positions(st.positions(), sim.pos, "out-of-box start")
+    st.ctx.sync()
+    st.close(); sim.close()
+
+
+def test_native_overfull_window_fails_loudly(gpe):
+    """More particles in a 24x24-cell window than the LDS cell window holds: sticky error, not silence."""
+    n = 40_000
+    world = (60.0, 60.0)                   # ~11 particles per unit^2
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=12)
+    st = _native(gpe, pos, rad, world)
+    st.update(1 / 60, resort=True)
+    with pytest.raises(gpe.GpeError) as e:
+        st.ctx.sync()
+    assert e.value.status == gpe._lib.GPE_ERR_UNSUPPORTED
+    st.close()
+
+
+def test_native_add_particles(gpe, oracle):
+    n = 4000
+    world = (220.0, 140.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=41)
+    extra_pos, extra_rad = gpe.scenes.mixed_radius_cloud(100, world, seed=42, radii=(1.0, 2.0, 3.0))
+    st = _native(gpe, pos, rad, world)
+    st.update(1 / 60, resort=True)
+    cur, prev, perm = st.positions(), st.previous_positions(), st.particles.download_particle_ids()
+    st.add_particles(extra_pos, extra_rad)
+    sim = oracle.Sim(np.concatenate([cur, extra_pos]), np.concatenate([rad[perm], extra_rad]),
+                     oracle.default_params(world[0], world[1], 3.0), prev=np.concatenate([prev, extra_pos]))
+    for s in range(6):
+        st.update(1 / 60, resort=(s == 3)); sim.step(1 / 60, resort=(s == 3))
+    _assert_positions(st.positions(), sim.pos, "positions after add_particles (native)")
+    st.close(); sim.close()
