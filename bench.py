@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
-    ap.add_argument("--mode", choices=["compat", "native"], default=os.environ.get("GPE_BENCH_MODE", "compat"))
+    ap.add_argument("--mode", choices=["compat", "native"], default=os.environ.get("GPE_BENCH_MODE", "native"))
     ap.add_argument("--gravity", choices=["off", "on"], default="off")
     ap.add_argument("--no-extra", action="store_true", help="skip the 100M-particle extra workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,6 +58,11 @@ def kernel_rooflines(timings, n_particles, mode):
         # name: (bytes per launch, description)
         "sort/scatter": (16 * pairs, "R key+payload 8 B, W key+payload 8 B per pair"),
         "sort/count": (4 * pairs, "R key 4 B per pair"),
+        "sort/onesweep": (16 * pairs, "one radix pass: R key+payload 8 B, W key+payload 8 B per pair"),
+        "sort/hist": (4 * pairs, "R key 4 B per pair"),
+        "native/hash": (12 * n, "R pos 8 B, W cell key 4 B per particle"),
+        "native/table": (8 * n, "R sorted key 4 B, W block bounds ~4 B per particle"),
+        "native/collide": (24 * n, "R pos 8 + radius 4 + id 4, W pos 8 per particle (SURVEY 8d collision row)"),
         "Build cell ids": (12 * n + 32 * n, "R pos 8 + radius 4, W 4 cell ids + 4 object ids"),
         "Particle integration pass": (36 * n, "R pos 8 + prev 8 + radius 4, W pos 8 + prev 8"),
         "Collision cell count objects per chunk": (16 * n + 4 * n, "R 4N keys, W N counts"),

@@ -243,7 +243,7 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
 {
     // state.rs:115-131
     if (flags & GPE_STEP_RESORT) GPE_TRY(do_resort(c));                          // :122-125
-    if (c->cfg.mode == GPE_MODE_NATIVE && c->native.eligible) {
+    if (native_should_run(c)) {
         // grid update + collision solve as N-key sort + LDS cell windows (k_native.hip); the resolved
         // positions land in the scratch set, which then becomes the live one
         GPE_TRY(native_collide(c, c->pos, c->pos_copy));
@@ -360,7 +360,7 @@ static gpe_status check_device_errors(gpe_ctx *c)
 {
     uint32_t words[2] = {0, 0};
     if (c->native.tile_ctl)
-        GPE_HIP(c, hipMemcpyAsync(&words[0], c->native.tile_ctl + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        GPE_HIP(c, hipMemcpyAsync(&words[0], c->native.tile_ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
     if (c->os_ws.ctl)
         GPE_HIP(c, hipMemcpyAsync(&words[1], c->os_ws.ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
@@ -591,11 +591,24 @@ gpe_status gpe_run(gpe_ctx *c, float dt, uint64_t steps, uint64_t resort_every, 
 {
     GPE_TRY(need_particles(c));
     GPE_HIP(c, hipSetDevice(c->device));
-    for (uint64_t s = 0; s < steps; ++s) {
+    // The host may run at most ~64 steps ahead of the device: bounds the queue and the lag of the
+    // device-side statistics the step policy reads (native_should_run).
+    hipEvent_t fence[2] = {nullptr, nullptr};
+    bool armed[2] = {false, false};
+    gpe_status rc = GPE_OK;
+    for (uint64_t s = 0; s < steps && rc == GPE_OK; ++s) {
+        if ((s & 31u) == 0 && steps > 64) {
+            const int slot = (int)((s >> 5) & 1u);
+            if (armed[slot]) (void)hipEventSynchronize(fence[slot]);
+            if (!fence[slot] && hipEventCreateWithFlags(&fence[slot], hipEventDisableTiming) != hipSuccess)
+                fence[slot] = nullptr;
+            if (fence[slot]) armed[slot] = hipEventRecord(fence[slot], c->stream) == hipSuccess;
+        }
         const bool resort = (s == 0 && resort_first) || (resort_every && s > 0 && (s % resort_every) == 0);
-        GPE_TRY(do_step(c, dt, resort ? GPE_STEP_RESORT : 0u));
+        rc = do_step(c, dt, resort ? GPE_STEP_RESORT : 0u);
     }
-    return GPE_OK;
+    for (hipEvent_t e : fence) if (e) (void)hipEventDestroy(e);
+    return rc;
 }
 
 // ---- downloads ---------------------------------------------------------------------------------------------

@@ -197,9 +197,14 @@ struct NativeState {
     uint32_t *keys = nullptr, *ids = nullptr;       // N each: hash output / sort ping
     uint32_t *keys_b = nullptr, *ids_b = nullptr;   // sort pong
     uint64_t cap = 0;
-    uint32_t *tile_ctl = nullptr;    // [0] overflow count (T=32 -> T=8), [1] error bits, [2] spill count
-    uint32_t *overflow_tiles = nullptr;             // packed (ty << 16 | tx) of tiles over capacity
+    uint32_t *tile_ctl = nullptr;    // device control words (k_native.hip kCtl*)
+    uint32_t *overflow1 = nullptr;   // packed (ty << 16 | tx) of 32x32 tiles over capacity
+    uint32_t *overflow2 = nullptr;   // ... of 16x16 tiles over capacity (4x as many slots)
     uint64_t overflow_cap = 0;
+    uint32_t *host_stat = nullptr;   // pinned: [0] last reported max 24x24-cell window population
+    uint32_t window_max = 0;         // the same, measured synchronously at configuration time
+    bool dense_hold = false;         // left the native path because windows were filling up
+    uint32_t steps_since_check = 0;
 };
 
 }  // namespace gpe
@@ -305,7 +310,7 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
                          uint32_t **out_vals);
 // native pipeline (k_native.hip)
 gpe_status native_configure(gpe_ctx *c);
-gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids);
+bool native_should_run(gpe_ctx *c);
 void native_release(gpe_ctx *c);
 gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out);
 // collision cells + solver

@@ -29,6 +29,16 @@ constexpr int kHalo = 8;                       // cells = one 8x8 Morton block
 constexpr uint32_t kErrOutOfBox = 1u;          // a particle outside the configured cell box
 constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS capacity (no result!)
 constexpr uint32_t kErrRegion = 4u;            // internal: particle outside its staged region
+// tile_ctl words (the first four are cleared every step, the error word is sticky)
+constexpr int kCtlOverflow1 = 0;               // 32x32 tiles over capacity this step
+constexpr int kCtlOverflow2 = 1;               // 16x16 tiles over capacity this step
+constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
+constexpr int kCtlError = 4;
+// tile sizes (cells) and LDS capacities (particles staged per region)
+constexpr int kTileMain = 32, kCapMain = 1536;
+constexpr int kTileMid = 16, kCapMid = 1920;
+constexpr int kTileSmall = 8, kCapSmall = 2048;
+constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows above this population
 
 // ---------------------------------------------------------------------------------------------------
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
@@ -61,13 +71,38 @@ __global__ __launch_bounds__(kNatThreads) void k_native_hash(const float2 *__res
 #pragma unroll
         for (int p = 0; p < 4; ++p) hist_add(s_hist + p * 256, (key >> (8 * p)) & 255u, valid);
     }
-    if (oob) atomicOr(&tile_ctl[1], kErrOutOfBox);
+    if (oob) atomicOr(&tile_ctl[kCtlError], kErrOutOfBox);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const uint32_t v = s_hist[p * 256 + threadIdx.x];
         if (v) atomicAdd(&hist4[p * 256 + threadIdx.x], v);
     }
+}
+
+// Largest particle count of any 3x3-block (24x24-cell) window: what the smallest cell window must hold.
+// Configuration-time check over the whole table (the step path gets the same number from the tiles).
+__global__ __launch_bounds__(kNatThreads) void k_native_window_max(const uint2 *__restrict__ table,
+                                                                    uint32_t entries, int32_t gx, int32_t gy,
+                                                                    uint32_t *__restrict__ out_max)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t best = 0;
+    for (uint64_t mb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; mb < entries; mb += stride) {
+        const int bx = (int)unsplit_by_bits((uint32_t)mb), by = (int)unsplit_by_bits((uint32_t)mb >> 1);
+        if (bx * 8 >= gx || by * 8 >= gy) continue;
+        uint32_t sum = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = bx + dx, y = by + dy;
+                if (x < 0 || y < 0 || x * 8 >= gx || y * 8 >= gy) continue;
+                const uint32_t m = morton_encode(x, y);
+                if (m < entries) { const uint2 se = table[m]; sum += se.y - se.x; }
+            }
+        best = max(best, sum);
+    }
+    for (int d = 32; d >= 1; d >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, d, 64));
+    if (lane_id() == 0 && best) atomicMax(out_max, best);
 }
 
 // every particle inside the cell box?  (configuration-time check, not on the step path)
@@ -118,9 +153,11 @@ struct CollideArgs {
     float stiffness;
     int32_t gx, gy;              // cell box
     int32_t tiles_x, tiles_y;    // tile grid of THIS kernel's tile size
-    uint32_t *tile_ctl;          // [0] overflow count, [1] error bits
-    uint32_t *overflow;          // packed (ty << 16 | tx) of over-capacity parent tiles
-    uint32_t overflow_cap;
+    uint32_t *tile_ctl;          // kCtl* words
+    uint32_t *overflow1;         // packed (ty << 16 | tx) of over-capacity 32x32 tiles
+    uint32_t overflow1_cap;
+    uint32_t *overflow2;         // ... of over-capacity 16x16 tiles
+    uint32_t overflow2_cap;
 };
 
 template <int T, int CAP>
@@ -140,6 +177,7 @@ struct TileLds {
     uint16_t list[NCELL];      // active cells, four colour segments of NCELL/4
     uint32_t lcnt[4];
     uint32_t bstart[NBLK];
+    uint32_t bcnt[NBLK];
     uint32_t boff[NBLK + 1];
     uint32_t s_w[4];
     uint32_t misc[4];
@@ -204,13 +242,13 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
             }
         }
         S.bstart[tid] = start;
-        S.boff[tid] = count;
+        S.bcnt[tid] = count;
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0, owned = 0;
         for (int b = 0; b < NBLK; ++b) {
-            const uint32_t cnt = S.boff[b];
+            const uint32_t cnt = S.bcnt[b];
             const int bi = b % NB, bj = b / NB;
             if (bi >= 1 && bi < NB - 1 && bj >= 1 && bj < NB - 1) owned += cnt;
             S.boff[b] = run;
@@ -219,6 +257,16 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
         S.boff[NBLK] = run;
         S.misc[0] = run;
         S.misc[1] = owned;
+    } else if (tid >= 64 && tid < 64 + (NB - 2) * (NB - 2)) {
+        // population of each 3x3-block window of this tile (what an 8x8-cell sub-tile would stage):
+        // the host reads the step's maximum (lagged) to leave the native path before windows overfill
+        const int wi = (tid - 64) % (NB - 2), wj = (tid - 64) / (NB - 2);
+        uint32_t w = 0;
+#pragma unroll
+        for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+            for (int di = 0; di < 3; ++di) w += S.bcnt[(wj + dj) * NB + wi + di];
+        if (w > kWindowReport) atomicMax(&A.tile_ctl[kCtlWindowMax], w);
     }
     __syncthreads();
     const uint32_t P = S.misc[0];
@@ -239,7 +287,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
         const int32_t cx = cell_coord(p.x, A.cell_size), cy = cell_coord(p.y, A.cell_size);
         int lx = cx - ox, ly = cy - oy;
         if (lx < 0 || lx >= RW || ly < 0 || ly >= RW) {                // cannot happen with a consistent table
-            atomicOr(&A.tile_ctl[1], kErrRegion);
+            atomicOr(&A.tile_ctl[kCtlError], kErrRegion);
             lx = min(max(lx, 0), RW - 1);
             ly = min(max(ly, 0), RW - 1);
         }
@@ -352,7 +400,8 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     return true;
 }
 
-// Dense launch: one workgroup per tile, tiles dealt so that each XCD (blockIdx % 8) works through a
+
+// Level 0: one workgroup per 32x32 tile, tiles dealt so that each XCD (blockIdx % 8) works through a
 // contiguous run of tile rows (neighbouring tiles share halo particles in that XCD's L2).
 template <int T, int CAP>
 __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
@@ -365,51 +414,57 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     const int tx = (int)(t % (uint32_t)A.tiles_x), ty = (int)(t / (uint32_t)A.tiles_x);
     if (!process_tile<T, CAP>(S, A, tx, ty)) {
         if (threadIdx.x == 0) {
-            const uint32_t slot = atomicAdd(&A.tile_ctl[0], 1u);
-            if (slot < A.overflow_cap) A.overflow[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
-            else atomicOr(&A.tile_ctl[1], kErrTileOverflow);
+            const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
+            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+            else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
         }
     }
 }
 
-// Over-capacity parents of size TP are redone as (TP/T)^2 sub-tiles of size T by a fixed grid.
-template <int T, int CAP, int TP>
+// Levels 1 and 2: the over-capacity parents (edge 2T) of the previous level are redone as four tiles of
+// edge T by a fixed grid that strides over the device-side list (HIP has no indirect dispatch).
+// LEVEL 1 reads overflow1 and spills to overflow2; LEVEL 2 reads overflow2 and has nowhere to spill.
+template <int T, int CAP, int LEVEL>
 __global__ __launch_bounds__(kNatThreads) void k_collide_sublist(CollideArgs A)
 {
     __shared__ TileLds<T, CAP> S;
-    constexpr int R = TP / T;
-    uint32_t count = A.tile_ctl[0];
-    if (count > A.overflow_cap) count = A.overflow_cap;
-    const uint32_t work = count * (uint32_t)(R * R);
+    const uint32_t *list = (LEVEL == 1) ? A.overflow1 : A.overflow2;
+    const uint32_t cap = (LEVEL == 1) ? A.overflow1_cap : A.overflow2_cap;
+    uint32_t count = A.tile_ctl[(LEVEL == 1) ? kCtlOverflow1 : kCtlOverflow2];
+    if (count > cap) count = cap;
+    const uint32_t work = count * 4u;
     for (uint32_t i = blockIdx.x; i < work; i += gridDim.x) {
-        const uint32_t parent = A.overflow[i / (R * R)];
-        const int sub = (int)(i % (R * R));
-        const int tx = (int)(parent & 0xFFFFu) * R + sub % R, ty = (int)(parent >> 16) * R + sub / R;
-        if (!process_tile<T, CAP>(S, A, tx, ty)) {
-            // no smaller tile: flag loudly (gpe_sync/gpe_download report it) and pass the tile's own
-            // particles through unresolved so that the state stays finite
-            if (threadIdx.x == 0) atomicOr(&A.tile_ctl[1], kErrTileOverflow);
+        const uint32_t parent = list[i >> 2];
+        const int sub = (int)(i & 3u);
+        const int tx = (int)(parent & 0xFFFFu) * 2 + (sub & 1), ty = (int)(parent >> 16) * 2 + (sub >> 1);
+        if (process_tile<T, CAP>(S, A, tx, ty)) continue;
+        if (LEVEL == 1) {
+            if (threadIdx.x == 0) {
+                const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow2], 1u);
+                if (slot < A.overflow2_cap) A.overflow2[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+                else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
+            }
+        } else {
+            // No smaller window exists: flag it (gpe_sync / gpe_download report the error) and pass the
+            // tile's own particles through unresolved so that the state stays finite.
+            if (threadIdx.x == 0) atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
             using L = TileLds<T, CAP>;
             for (int b = threadIdx.x; b < L::NBLK; b += kNatThreads) {
                 const int bi = b % L::NB, bj = b / L::NB;
                 if (bi < 1 || bi >= L::NB - 1 || bj < 1 || bj >= L::NB - 1) continue;
-                const uint32_t n_b = S.boff[b + 1] - S.boff[b];
-                for (uint32_t q = 0; q < n_b; ++q) {
+                for (uint32_t q = 0; q < S.bcnt[b]; ++q) {
                     const uint32_t id = A.sorted_ids[S.bstart[b] + q];
                     A.pos_out[id] = A.pos_in[id];
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-constexpr int kTileMain = 32, kCapMain = 1536;
-constexpr int kTileSub = 8, kCapSub = 2048;
-
 static uint32_t host_split(uint32_t n)
 {
     uint32_t x = n & 0x0000FFFFu;
@@ -429,17 +484,50 @@ void native_release(gpe_ctx *c)
     if (N.keys_b) (void)hipFree(N.keys_b);
     if (N.ids_b) (void)hipFree(N.ids_b);
     if (N.tile_ctl) (void)hipFree(N.tile_ctl);
-    if (N.overflow_tiles) (void)hipFree(N.overflow_tiles);
+    if (N.overflow1) (void)hipFree(N.overflow1);
+    if (N.overflow2) (void)hipFree(N.overflow2);
+    if (N.host_stat) (void)hipHostFree(N.host_stat);
     N = NativeState();
 }
 
+// hash -> sort -> block table.  *sorted_ids receives the particle ids in Morton order of their home cell.
+static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
+{
+    NativeState &N = c->native;
+    const uint64_t n = c->n;
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 16, c->stream));         // per-step words; the error word stays
+    GPE_HIP(c, hipMemsetAsync(N.block_table, 0, (size_t)N.table_entries * sizeof(uint2), c->stream));
+    GPE_TRY(onesweep_zero_hist(c));
+    {
+        Scope s(c, "native/hash");
+        hipLaunchKernelGGL(k_native_hash, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, c->pos, n,
+                           c->cell_size, N.gx, N.gy, N.keys, c->os_ws.hist4, N.tile_ctl);
+        GPE_HIP(c, hipGetLastError());
+    }
+    uint32_t *sk = nullptr, *sv = nullptr;
+    {
+        Scope s(c, "native/sort");
+        GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv));
+    }
+    {
+        Scope s(c, "native/table");
+        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, sk, n,
+                           N.block_table, N.table_entries);
+        GPE_HIP(c, hipGetLastError());
+    }
+    *sorted_ids = sv;
+    return GPE_OK;
+}
+
 // (Re)derive the cell box from the world and the cell size, size the workspaces, and check on the
-// device that every particle lies inside the box.  Called from the configuration entry points
-// (set/add particles, set world, set max radius) -- never on the step path; synchronises.
+// device that (a) every particle lies inside the box and (b) no 24x24-cell window holds more particles
+// than the smallest LDS cell window stages.  Called from the configuration entry points (set/add
+// particles, set world, set max radius, set mode) -- never on the step path; synchronises.
 gpe_status native_configure(gpe_ctx *c)
 {
     NativeState &N = c->native;
     N.eligible = false;
+    N.steps_since_check = 0;
     if (c->n == 0 || !(c->cell_size > 0.0f)) return GPE_OK;
     // largest home coordinate a clamped particle can take: floor(world / cell_size)
     // (K12 clamps to [r, world - r], particle_integration.wgsl:70-71)
@@ -471,52 +559,68 @@ gpe_status native_configure(gpe_ctx *c)
     }
     const uint64_t tiles = (uint64_t)((N.gx + kTileMain - 1) / kTileMain) * ((N.gy + kTileMain - 1) / kTileMain);
     if (N.overflow_cap < tiles) {
-        if (N.overflow_tiles) GPE_HIP(c, hipFree(N.overflow_tiles));
-        N.overflow_tiles = nullptr; N.overflow_cap = 0;
-        GPE_HIP(c, hipMalloc((void **)&N.overflow_tiles, (tiles + 16) * sizeof(uint32_t)));
+        if (N.overflow1) GPE_HIP(c, hipFree(N.overflow1));
+        if (N.overflow2) GPE_HIP(c, hipFree(N.overflow2));
+        N.overflow1 = N.overflow2 = nullptr; N.overflow_cap = 0;
+        GPE_HIP(c, hipMalloc((void **)&N.overflow1, (tiles + 16) * sizeof(uint32_t)));
+        GPE_HIP(c, hipMalloc((void **)&N.overflow2, (4 * tiles + 16) * sizeof(uint32_t)));
         N.overflow_cap = tiles;
     }
     if (!N.tile_ctl) GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, 64));
+    if (!N.host_stat) GPE_HIP(c, hipHostMalloc((void **)&N.host_stat, 64, hipHostMallocDefault));
+    N.host_stat[0] = 0;
     GPE_TRY(onesweep_reserve(c, c->cap));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
     hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kNatThreads), 0, c->stream, c->pos, c->n,
-                       c->cell_size, N.gx, N.gy, N.tile_ctl + 1);
+                       c->cell_size, N.gx, N.gy, N.tile_ctl + kCtlError);
     GPE_HIP(c, hipGetLastError());
     uint32_t flag = 1;
-    GPE_HIP(c, hipMemcpyAsync(&flag, N.tile_ctl + 1, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipMemcpyAsync(&flag, N.tile_ctl + kCtlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));         // the check's verdict is not a step error
-    N.eligible = (flag == 0);
+    if (flag != 0) return GPE_OK;                                      // a particle outside the box: compat kernels
+    // window population of the current state
+    const bool prof = c->profiling;
+    c->profiling = false;
+    uint32_t *ids = nullptr;
+    gpe_status st = native_prepare_step(c, &ids);
+    c->profiling = prof;
+    GPE_TRY(st);
+    hipLaunchKernelGGL(k_native_window_max, dim3(stream_grid(N.table_entries)), dim3(kNatThreads), 0, c->stream,
+                       N.block_table, N.table_entries, N.gx, N.gy, N.tile_ctl + kCtlWindowMax);
+    GPE_HIP(c, hipGetLastError());
+    uint32_t wmax = 0xffffffffu;
+    GPE_HIP(c, hipMemcpyAsync(&wmax, N.tile_ctl + kCtlWindowMax, sizeof(wmax), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
+    N.window_max = wmax;
+    N.eligible = wmax <= (uint32_t)kCapSmall;
     return GPE_OK;
 }
 
-// hash -> sort -> block table.  *sorted_ids receives the particle ids in Morton order of their home cell.
-gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
+// Should this step take the native kernels?  The tiles report the step's largest 24x24-cell window
+// population to pinned host memory (asynchronously, so the value lags by the steps still in flight;
+// gpe_run bounds that).  Above 3/4 of the smallest window's capacity the context leaves the native path
+// before a window can overfill, and re-evaluates (synchronously) every 256 steps.
+bool native_should_run(gpe_ctx *c)
 {
     NativeState &N = c->native;
-    const uint64_t n = c->n;
-    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 4, c->stream));          // overflow count; error bits stay sticky
-    GPE_HIP(c, hipMemsetAsync(N.block_table, 0, (size_t)N.table_entries * sizeof(uint2), c->stream));
-    GPE_TRY(onesweep_zero_hist(c));
-    {
-        Scope s(c, "native/hash");
-        hipLaunchKernelGGL(k_native_hash, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, c->pos, n,
-                           c->cell_size, N.gx, N.gy, N.keys, c->os_ws.hist4, N.tile_ctl);
-        GPE_HIP(c, hipGetLastError());
+    if (c->cfg.mode != GPE_MODE_NATIVE) return false;
+    if (N.eligible) {
+        if (N.host_stat && N.host_stat[0] > (uint32_t)(kCapSmall / 4 * 3)) {
+            N.eligible = false;
+            N.dense_hold = true;
+            N.steps_since_check = 0;
+        }
+        return N.eligible;
     }
-    uint32_t *sk = nullptr, *sv = nullptr;
-    {
-        Scope s(c, "native/sort");
-        GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv));
+    if (N.dense_hold && ++N.steps_since_check >= 256) {
+        N.dense_hold = false;
+        if (native_configure(c) != GPE_OK) return false;
+        if (!N.eligible) N.dense_hold = true;
+        return N.eligible;
     }
-    {
-        Scope s(c, "native/table");
-        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, sk, n,
-                           N.block_table, N.table_entries);
-        GPE_HIP(c, hipGetLastError());
-    }
-    *sorted_ids = sv;
-    return GPE_OK;
+    return false;
 }
 
 // pos_in (step-start positions) -> pos_out (after the four colour passes), every particle written.
@@ -537,8 +641,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     A.gx = N.gx;
     A.gy = N.gy;
     A.tile_ctl = N.tile_ctl;
-    A.overflow = N.overflow_tiles;
-    A.overflow_cap = (uint32_t)N.overflow_cap;
+    A.overflow1 = N.overflow1;
+    A.overflow1_cap = (uint32_t)N.overflow_cap;
+    A.overflow2 = N.overflow2;
+    A.overflow2_cap = (uint32_t)(4 * N.overflow_cap);
     {
         Scope s(c, "native/collide");
         A.tiles_x = (N.gx + kTileMain - 1) / kTileMain;
@@ -549,13 +655,16 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
         GPE_HIP(c, hipGetLastError());
     }
     {
+        // tiles whose 48x48-cell region exceeded the LDS capacity: 16x16 tiles, then 8x8 tiles
         Scope s(c, "native/collide-dense-regions");
-        A.tiles_x = (N.gx + kTileSub - 1) / kTileSub;
-        A.tiles_y = (N.gy + kTileSub - 1) / kTileSub;
-        hipLaunchKernelGGL((k_collide_sublist<kTileSub, kCapSub, kTileMain>), dim3(512), dim3(kNatThreads), 0,
-                           c->stream, A);
+        hipLaunchKernelGGL((k_collide_sublist<kTileMid, kCapMid, 1>), dim3(512), dim3(kNatThreads), 0, c->stream, A);
+        GPE_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL((k_collide_sublist<kTileSmall, kCapSmall, 2>), dim3(512), dim3(kNatThreads), 0, c->stream,
+                           A);
         GPE_HIP(c, hipGetLastError());
     }
+    GPE_HIP(c, hipMemcpyAsync(N.host_stat, N.tile_ctl + kCtlWindowMax, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              c->stream));
     return GPE_OK;
 }
 
