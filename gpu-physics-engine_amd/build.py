@@ -19,7 +19,7 @@ ARCH = "gfx950"
 CXXFLAGS = [
     "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off",
     "-fno-fast-math", "-Wall", "-Wno-unused-function",
-]
+] + os.environ.get("GPE_EXTRA_CXXFLAGS", "").split()     # e.g. -DGPE_TILE_STAMPS for the diagnostic build
 
 
 def sources():

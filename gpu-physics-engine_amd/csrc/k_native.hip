@@ -20,6 +20,8 @@
 // inputs, same operation order => same bits), so no inter-tile communication and no global colour
 // barrier is needed.  Positions are double-buffered (read pos_in, write pos_out) because neighbours
 // read a tile's step-start positions while it writes its results.
+#include <stdio.h>
+
 #include "gpe_internal.h"
 
 namespace gpe {
@@ -35,7 +37,7 @@ constexpr int kCtlOverflow2 = 1;               // 16x16 tiles over capacity this
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
 constexpr int kCtlError = 4;
 // tile sizes (cells) and LDS capacities (particles staged per region)
-constexpr int kTileMain = 32, kCapMain = 1536;
+constexpr int kTileMain = 32, kCapMain = 1152;
 constexpr int kTileMid = 16, kCapMid = 1920;
 constexpr int kTileSmall = 8, kCapSmall = 2048;
 constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows above this population
@@ -158,7 +160,24 @@ struct CollideArgs {
     uint32_t overflow1_cap;
     uint32_t *overflow2;         // ... of over-capacity 16x16 tiles
     uint32_t overflow2_cap;
+    unsigned long long *stamps;  // diagnostic builds only (-DGPE_TILE_STAMPS): cycles per phase, thread 0
 };
+
+#ifdef GPE_TILE_STAMPS
+#define GPE_STAMP_BEGIN() long long _t_prev = clock64()
+#define GPE_STAMP(i)                                                                  \
+    do {                                                                              \
+        if (A.stamps && threadIdx.x == 0 && (blockIdx.x & 127u) == 5u) {                  \
+            const long long _t = clock64();                                           \
+            atomicAdd(&A.stamps[i], (unsigned long long)(_t - _t_prev));              \
+            atomicAdd(&A.stamps[16 + (i)], 1ull);                                      \
+            _t_prev = _t;                                                             \
+        }                                                                             \
+    } while (0)
+#else
+#define GPE_STAMP_BEGIN() do {} while (0)
+#define GPE_STAMP(i) do {} while (0)
+#endif
 
 template <int T, int CAP>
 struct TileLds {
@@ -167,14 +186,18 @@ struct TileLds {
     static constexpr int NB = RW / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
+    static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads;    // particles per thread
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
-    uint16_t home[CAP];        // local index of the home cell
-    uint16_t mcode[CAP];       // phantom cells: count in bits 12-13, 4-bit neighbour codes in bits 0-11
-    uint32_t cnt[NCELL];       // members per cell (then: fill cursor counting down to 0)
+    uint32_t hm[CAP];          // bits 0-15 local index of the home cell; bits 16-27 phantom-cell codes
+                               // (3 x 4 bit, (dy+1)*3+(dx+1)); bits 28-29 number of phantom cells
+    uint8_t sblk[CAP];         // region block a staged slot came from
+    union {
+        uint32_t cnt[NCELL];   // P1-P3: members per cell, then fill cursor counting down to 0
+        uint16_t list[NCELL];  // P4-P5: active cells, four colour segments of NCELL/4
+    };
     uint16_t cstart[NCELL + 2];
     uint16_t mem[4 * CAP];     // member lists (local particle slots)
-    uint16_t list[NCELL];      // active cells, four colour segments of NCELL/4
     uint32_t lcnt[4];
     uint32_t bstart[NBLK];
     uint32_t bcnt[NBLK];
@@ -183,19 +206,58 @@ struct TileLds {
     uint32_t misc[4];
 };
 
-// The reference's pair resolution (collision_solver.wgsl:85-111), on LDS-resident positions.
+// Members of one cell into ascending object index (the order the reference's stable sort gives them).
+template <class L>
+__device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint32_t e)
+{
+    const uint32_t n = e - b;
+    if (n == 2) {
+        const uint16_t m0 = S.mem[b], m1 = S.mem[b + 1];
+        if (S.id[m0] > S.id[m1]) { S.mem[b] = m1; S.mem[b + 1] = m0; }
+        return;
+    }
+    if (n == 3) {
+        uint16_t m0 = S.mem[b], m1 = S.mem[b + 1], m2 = S.mem[b + 2];
+        uint32_t i0 = S.id[m0], i1 = S.id[m1], i2 = S.id[m2];
+        bool ch = false;
+        if (i0 > i1) { uint16_t t = m0; m0 = m1; m1 = t; uint32_t u = i0; i0 = i1; i1 = u; ch = true; }
+        if (i1 > i2) { uint16_t t = m1; m1 = m2; m2 = t; uint32_t u = i1; i1 = i2; i2 = u; ch = true; }
+        if (i0 > i1) { uint16_t t = m0; m0 = m1; m1 = t; ch = true; }
+        if (ch) { S.mem[b] = m0; S.mem[b + 1] = m1; S.mem[b + 2] = m2; }
+        return;
+    }
+    for (uint32_t i = b + 1; i < e; ++i) {                             // insertion sort
+        const uint16_t x = S.mem[i];
+        const uint32_t kx = S.id[x];
+        uint32_t j = i;
+        while (j > b && S.id[S.mem[j - 1]] > kx) { S.mem[j] = S.mem[j - 1]; --j; }
+        S.mem[j] = x;
+    }
+}
+
+// The reference's pair resolution (collision_solver.wgsl:66-118), on LDS-resident positions.
+// Bit-exact restatements used to shorten the dependent chain of the sequential pair loop:
+//  * the next partner's position is fetched while the current pair is computed: within one `a` loop
+//    every pair touches a different partner, so that position cannot change in between;
+//  * inv_mass_1 (:103) is the same value for every pair of `a` and is computed once;
+//  * r1 == r2 (and 1/r finite, non-zero): inv1 == inv2 and inv1 + inv1 == 2*inv1 exactly, so both
+//    weights (:107-108) are exactly 0.5 -- the three divisions are skipped, not approximated.
 template <class L>
 __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint32_t e, const float stiffness)
 {
     for (uint32_t ia = b; ia + 1 < e; ++ia) {                         // :68
         const uint32_t a = S.mem[ia];
+        uint32_t nb = S.mem[ia + 1];
         float p1x = S.px[a], p1y = S.py[a];
         const float r1 = S.rad[a];
+        float nx = S.px[nb], ny = S.py[nb], nr = S.rad[nb];
+        const float inv1 = 1.0f / r1;                                 // :103
+        const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
         bool dirty = false;
         for (uint32_t ib = ia + 1; ib < e; ++ib) {                    // :77
-            const uint32_t bb = S.mem[ib];
-            const float p2x = S.px[bb], p2y = S.py[bb];               // :86 live position
-            const float r2 = S.rad[bb];
+            const uint32_t bb = nb;
+            const float p2x = nx, p2y = ny, r2 = nr;                  // :86 live position
+            if (ib + 1 < e) { nb = S.mem[ib + 1]; nx = S.px[nb]; ny = S.py[nb]; nr = S.rad[nb]; }
             const float vx = p1x - p2x, vy = p1y - p2y;               // :91
             const float distance = sqrtf(vx * vx + vy * vy);          // :93
             const float radius_sum = r1 + r2;                         // :61
@@ -203,9 +265,14 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
                 const float depth = radius_sum - distance;            // :97
                 const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
                 const float cy = ((vy / distance) * depth) * stiffness;
-                const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;       // :103-104
-                const float w1 = inv1 / (inv1 + inv2);                // :107
-                const float w2 = inv2 / (inv1 + inv2);                // :108
+                float w1, w2;
+                if (r1 == r2 && r1_plain) {
+                    w1 = 0.5f; w2 = 0.5f;                             // == inv1 / (inv1 + inv1), exactly
+                } else {
+                    const float inv2 = 1.0f / r2;                     // :104
+                    w1 = inv1 / (inv1 + inv2);                        // :107
+                    w2 = inv2 / (inv1 + inv2);                        // :108
+                }
                 p1x = p1x + cx * w1;                                  // :110
                 p1y = p1y + cy * w1;
                 S.px[bb] = p2x - cx * w2;                             // :111
@@ -222,11 +289,14 @@ template <int T, int CAP>
 __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int tx, const int ty)
 {
     using L = TileLds<T, CAP>;
-    constexpr int RW = L::RW, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER;
+    constexpr int RW = L::RW, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
+    static_assert(NBLK <= 255, "sblk is 8 bit");
     const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
     const int ox = tx * T - kHalo, oy = ty * T - kHalo;                // region origin (cells)
+    GPE_STAMP_BEGIN();
 
-    // ---- P0: clear, look the region's blocks up ---------------------------------------------------
+    // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
     for (int i = tid; i < NCELL; i += kNatThreads) S.cnt[i] = 0;
     if (tid < 4) S.lcnt[tid] = 0;
     if (tid < NBLK) {
@@ -245,19 +315,23 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
         S.bcnt[tid] = count;
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0, owned = 0;
-        for (int b = 0; b < NBLK; ++b) {
-            const uint32_t cnt = S.bcnt[b];
-            const int bi = b % NB, bj = b / NB;
-            if (bi >= 1 && bi < NB - 1 && bj >= 1 && bj < NB - 1) owned += cnt;
-            S.boff[b] = run;
-            run += cnt;
+    if (tid < 64) {
+        // exclusive scan of the block populations by one wave; particles of the tile's own blocks
+        uint32_t carry = 0, own = 0;
+        for (int base = 0; base < NBLK; base += 64) {
+            const int b = base + lane;
+            const uint32_t cb = (b < NBLK) ? S.bcnt[b] : 0u;
+            const uint32_t inc = wave_inclusive_scan(cb);
+            if (b < NBLK) {
+                S.boff[b] = carry + inc - cb;
+                const int bi = b % NB, bj = b / NB;
+                if (bi >= 1 && bi < NB - 1 && bj >= 1 && bj < NB - 1) own += cb;
+            }
+            carry += __shfl(inc, 63, 64);
         }
-        S.boff[NBLK] = run;
-        S.misc[0] = run;
-        S.misc[1] = owned;
-    } else if (tid >= 64 && tid < 64 + (NB - 2) * (NB - 2)) {
+        for (int d = 32; d >= 1; d >>= 1) own += __shfl_xor(own, d, 64);
+        if (lane == 0) { S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[1] = own; }
+    } else if (tid < 64 + (NB - 2) * (NB - 2)) {
         // population of each 3x3-block window of this tile (what an 8x8-cell sub-tile would stage):
         // the host reads the step's maximum (lagged) to leave the native path before windows overfill
         const int wi = (tid - 64) % (NB - 2), wj = (tid - 64) / (NB - 2);
@@ -272,50 +346,99 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     const uint32_t P = S.misc[0];
     if (S.misc[1] == 0) return true;                                   // nothing of its own to write
     if (P > (uint32_t)CAP) return false;
-
-    // ---- P1: gather the region's particles, count cell memberships -------------------------------
-    for (uint32_t s = tid; s < P; s += kNatThreads) {
-        int lo = 0, hi = NBLK;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (S.boff[mid] <= s) lo = mid; else hi = mid;
+    {
+        // slot -> block map: kNatThreads / NBLK threads share each block's slots
+        constexpr int SHARE = (kNatThreads / NBLK) > 0 ? (kNatThreads / NBLK) : 1;
+        for (int b = tid % NBLK, sub = tid / NBLK; sub < SHARE && b < NBLK; b += kNatThreads) {
+            const uint32_t lo = S.boff[b], hi = S.boff[b + 1];
+            for (uint32_t i = lo + sub; i < hi; i += SHARE) S.sblk[i] = (uint8_t)b;
         }
-        const uint32_t j = S.bstart[lo] + (s - S.boff[lo]);
-        const uint32_t id = A.sorted_ids[j];
-        const float2 p = A.pos_in[id];
-        const float r = A.radius[id];
-        const int32_t cx = cell_coord(p.x, A.cell_size), cy = cell_coord(p.y, A.cell_size);
-        int lx = cx - ox, ly = cy - oy;
-        if (lx < 0 || lx >= RW || ly < 0 || ly >= RW) {                // cannot happen with a consistent table
-            atomicOr(&A.tile_ctl[kCtlError], kErrRegion);
-            lx = min(max(lx, 0), RW - 1);
-            ly = min(max(ly, 0), RW - 1);
-        }
-        S.px[s] = p.x; S.py[s] = p.y; S.rad[s] = r; S.id[s] = id;
-        const int home = ly * RW + lx;
-        S.home[s] = (uint16_t)home;
-        atomicAdd(&S.cnt[home], 1u);
-        // phantom cells in the reference's scan order (grid.wgsl:68-90), at most three kept
-        const float sq = r * r;
-        uint32_t code = 0, pc = 0;
-#pragma unroll
-        for (int y = -1; y <= 1; ++y) {
-#pragma unroll
-            for (int x = -1; x <= 1; ++x) {
-                if (x == 0 && y == 0) continue;
-                if (is_obj_in_cell(p.x, p.y, sq, cx + x, cy + y, A.cell_size)) {
-                    if (pc < 3) {
-                        code |= (uint32_t)((y + 1) * 3 + (x + 1)) << (4 * pc);
-                        const int nlx = lx + x, nly = ly + y;
-                        if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) atomicAdd(&S.cnt[nly * RW + nlx], 1u);
-                    }
-                    ++pc;
-                }
-            }
-        }
-        S.mcode[s] = (uint16_t)(code | ((pc < 3 ? pc : 3u) << 12));
     }
     __syncthreads();
+    GPE_STAMP(0);
+
+    // ---- P1: gather the region's particles (all loads of a thread in flight together), count the
+    //          cell memberships -----------------------------------------------------------------------
+    {
+        uint32_t pid[QMAX];
+        float2 pp[QMAX];
+        float pr[QMAX];
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            pid[q] = 0;
+            if (s < P) {
+                const uint32_t b = S.sblk[s];
+                pid[q] = A.sorted_ids[S.bstart[b] + (s - S.boff[b])];
+            }
+        }
+#ifdef GPE_TILE_STAMPS
+        { uint32_t acc = 0; for (int q = 0; q < QMAX; ++q) acc += pid[q]; asm volatile("" :: "v"(acc)); }
+        GPE_STAMP(7);
+#endif
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            pp[q] = make_float2(0.f, 0.f);
+            pr[q] = 0.f;
+            if (s < P) { pp[q] = A.pos_in[pid[q]]; pr[q] = A.radius[pid[q]]; }
+        }
+#ifdef GPE_TILE_STAMPS
+        { float acc = 0; for (int q = 0; q < QMAX; ++q) acc += pp[q].x + pr[q]; asm volatile("" :: "v"(acc)); }
+        GPE_STAMP(8);
+#endif
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            if (s >= P) continue;
+            const float2 p = pp[q];
+            const float r = pr[q];
+            const int32_t cx = cell_coord(p.x, A.cell_size), cy = cell_coord(p.y, A.cell_size);
+            int lx = cx - ox, ly = cy - oy;
+            if (lx < 0 || lx >= RW || ly < 0 || ly >= RW) {            // cannot happen with a consistent table
+                atomicOr(&A.tile_ctl[kCtlError], kErrRegion);
+                lx = min(max(lx, 0), RW - 1);
+                ly = min(max(ly, 0), RW - 1);
+            }
+            S.px[s] = p.x; S.py[s] = p.y; S.rad[s] = r; S.id[s] = pid[q];
+            const int home = ly * RW + lx;
+            atomicAdd(&S.cnt[home], 1u);
+            // phantom cells in the reference's scan order (grid.wgsl:68-90), at most three kept.
+            // is_obj_in_cell (grid.wgsl:117-129) per axis: the clamped offset of neighbour column i /
+            // row j does not depend on the other axis, so the 8 tests share 3 + 3 squared offsets
+            // (same operations and order as dot(d, d) = d.x*d.x + d.y*d.y).
+            const float sq = r * r;
+            float sx[3], sy[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float lo_x = (float)(cx + i - 1) * A.cell_size, lo_y = (float)(cy + i - 1) * A.cell_size;
+                const float dx = p.x - clamp_f(p.x, lo_x, lo_x + A.cell_size);
+                const float dy = p.y - clamp_f(p.y, lo_y, lo_y + A.cell_size);
+                sx[i] = dx * dx;
+                sy[i] = dy * dy;
+            }
+            uint32_t code = 0, pc = 0;
+#pragma unroll
+            for (int y = -1; y <= 1; ++y) {
+#pragma unroll
+                for (int x = -1; x <= 1; ++x) {
+                    if (x == 0 && y == 0) continue;
+                    if (sx[x + 1] + sy[y + 1] < sq) {
+                        if (pc < 3) {
+                            code |= (uint32_t)((y + 1) * 3 + (x + 1)) << (4 * pc);
+                            const int nlx = lx + x, nly = ly + y;
+                            if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW)
+                                atomicAdd(&S.cnt[nly * RW + nlx], 1u);
+                        }
+                        ++pc;
+                    }
+                }
+            }
+            S.hm[s] = (uint32_t)home | (code << 16) | ((pc < 3 ? pc : 3u) << 28);
+        }
+    }
+    __syncthreads();
+    GPE_STAMP(1);
 
     // ---- P2: exclusive scan of the per-cell counts -> list starts ----------------------------------
     {
@@ -332,17 +455,18 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
         if (tid == 0) S.cstart[NCELL] = (uint16_t)total;
     }
     __syncthreads();
+    GPE_STAMP(2);
 
     // ---- P3: fill the member lists (order fixed later by the per-cell sort) --------------------------
     for (uint32_t s = tid; s < P; s += kNatThreads) {
-        const int home = S.home[s];
+        const uint32_t hm = S.hm[s];
+        const int home = (int)(hm & 0xFFFFu);
         uint32_t k = atomicSub(&S.cnt[home], 1u) - 1u;
         S.mem[S.cstart[home] + k] = (uint16_t)s;
-        const uint32_t code = S.mcode[s];
-        const uint32_t pc = code >> 12;
+        const uint32_t pc = hm >> 28;
         const int lx = home % RW, ly = home / RW;
         for (uint32_t q = 0; q < pc; ++q) {
-            const int nb = (int)((code >> (4 * q)) & 15u);
+            const int nb = (int)((hm >> (16 + 4 * q)) & 15u);
             const int nlx = lx + (nb % 3) - 1, nly = ly + (nb / 3) - 1;
             if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) {
                 const int lc = nly * RW + nlx;
@@ -351,32 +475,45 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
             }
         }
     }
-    __syncthreads();
+    __syncthreads();          // cnt is all zero again and dead from here on: `list` takes its storage
+    GPE_STAMP(3);
 
-    // ---- P4: active cells per colour; members into ascending object index ---------------------------
-    for (int lc = tid; lc < NCELL; lc += kNatThreads) {
-        const uint32_t b = S.cstart[lc], e = S.cstart[lc + 1];
-        if (e - b < 2) continue;
-        const int lx = lc % RW, ly = lc / RW;
-        const int gxx = ox + lx, gyy = oy + ly;
-        // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
-        // (collision_cell_builder.wgsl:56)
-        if (((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF)) continue;
-        const int k = (gxx & 1) + 2 * (gyy & 1);                       // colour - 1 (collision_solver.wgsl:55-58)
-        const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
-        const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
-        if (max(ex, ey) > 4 - k) continue;                             // outside the colour's exactness zone
-        for (uint32_t i = b + 1; i < e; ++i) {                         // insertion sort by object index
-            const uint16_t x = S.mem[i];
-            const uint32_t kx = S.id[x];
-            uint32_t j = i;
-            while (j > b && S.id[S.mem[j - 1]] > kx) { S.mem[j] = S.mem[j - 1]; --j; }
-            S.mem[j] = x;
+    // ---- P4: active cells per colour.  Colour-major walk: every wave round looks at 64 cells of ONE
+    //          colour, so one ballot and one LDS atomic per round compact them ---------------------------
+    {
+        constexpr int HW = RW / 2, QC = NCELL / 4;                     // cells of one colour: HW x HW
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox, oy are even
+            const int px0 = c & 1, py0 = c >> 1;
+            for (int base = 0; base < QC; base += kNatThreads) {
+                const int i = base + tid;
+                bool act = false;
+                int lc = 0;
+                if (i < QC) {
+                    const int lx = 2 * (i % HW) + px0, ly = 2 * (i / HW) + py0;
+                    lc = ly * RW + lx;
+                    const uint32_t b = S.cstart[lc], e = S.cstart[lc + 1];
+                    const int gxx = ox + lx, gyy = oy + ly;
+                    const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
+                    const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
+                    // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
+                    // (collision_cell_builder.wgsl:56); cells outside the colour's exactness zone are skipped
+                    const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
+                    act = (e - b >= 2) && !unused_alias && (max(ex, ey) <= 4 - c);
+                }
+                const uint64_t m = __ballot(act);
+                if (m == 0) continue;
+                const int leader = (int)__builtin_ctzll(m);
+                uint32_t basei = 0;
+                if (lane == leader) basei = atomicAdd(&S.lcnt[c], (uint32_t)__popcll(m));
+                basei = __shfl(basei, leader, 64);
+                if (act) S.list[c * QC + basei + popc_below_lane(m)] = (uint16_t)lc;
+            }
         }
-        const uint32_t idx = atomicAdd(&S.lcnt[k], 1u);
-        S.list[k * (NCELL / 4) + idx] = (uint16_t)lc;
     }
     __syncthreads();
+    GPE_STAMP(4);
 
     // ---- P5: the four colour passes (collision_solver.rs:224), one lane per collision cell ----------
 #pragma unroll 1
@@ -384,19 +521,26 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
         const uint32_t nk = S.lcnt[k];
         for (uint32_t i = tid; i < nk; i += kNatThreads) {
             const int lc = S.list[k * (NCELL / 4) + i];
-            resolve_cell(S, S.cstart[lc], S.cstart[lc + 1], A.stiffness);
+            const uint32_t b = S.cstart[lc], e = S.cstart[lc + 1];
+            sort_members(S, b, e);
+            resolve_cell(S, b, e, A.stiffness);
         }
+#ifdef GPE_TILE_STAMPS
+        GPE_STAMP(9 + k);
+#endif
         __syncthreads();
     }
+    GPE_STAMP(5);
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
     for (uint32_t s = tid; s < P; s += kNatThreads) {
-        const int home = S.home[s];
+        const int home = (int)(S.hm[s] & 0xFFFFu);
         const int lx = home % RW, ly = home / RW;
         if (lx >= kHalo && lx < kHalo + T && ly >= kHalo && ly < kHalo + T)
             A.pos_out[S.id[s]] = make_float2(S.px[s], S.py[s]);
     }
     __syncthreads();
+    GPE_STAMP(6);
     return true;
 }
 
@@ -645,6 +789,22 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     A.overflow1_cap = (uint32_t)N.overflow_cap;
     A.overflow2 = N.overflow2;
     A.overflow2_cap = (uint32_t)(4 * N.overflow_cap);
+    A.stamps = nullptr;
+#ifdef GPE_TILE_STAMPS
+    static unsigned long long *g_stamps = nullptr;
+    if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 32 * 8); (void)hipMemset(g_stamps, 0, 32 * 8); }
+    A.stamps = g_stamps;
+    static int g_calls = 0;
+    if (++g_calls % 20 == 0) {
+        unsigned long long h[32];
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(h, g_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[tile stamps] n=%llu", (unsigned long long)c->n);
+        for (int i = 0; i < 14; ++i) fprintf(stderr, "  P%d %.0f", i, h[16 + i] ? (double)h[i] / (double)h[16 + i] : 0.0);
+        fprintf(stderr, "  (tiles %llu)\n", h[16 + 6]);
+        (void)hipMemset(g_stamps, 0, 32 * 8);
+    }
+#endif
     {
         Scope s(c, "native/collide");
         A.tiles_x = (N.gx + kTileMain - 1) / kTileMain;
