@@ -24,9 +24,34 @@
 
 #include "gpe_internal.h"
 
+#ifndef GPE_NAT_THREADS
+#define GPE_NAT_THREADS 512
+#endif
+
 namespace gpe {
 
-constexpr int kNatThreads = 256;
+constexpr int kNatThreads = GPE_NAT_THREADS;
+constexpr int kNatWaves = kNatThreads / 64;
+
+// exclusive scan of one value per thread over the whole workgroup (kNatWaves waves)
+__device__ __forceinline__ uint32_t nat_block_exclusive_scan(uint32_t v, uint32_t *s_w, uint32_t *total)
+{
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < kNatWaves; ++i) {
+        const uint32_t x = s_w[i];
+        if (i < w) base += x;
+        all += x;
+    }
+    if (total) *total = all;
+    __syncthreads();
+    return base + inc - v;
+}
 constexpr int kHalo = 8;                       // cells = one 8x8 Morton block
 constexpr uint32_t kErrOutOfBox = 1u;          // a particle outside the configured cell box
 constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS capacity (no result!)
@@ -37,7 +62,7 @@ constexpr int kCtlOverflow2 = 1;               // 16x16 tiles over capacity this
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
 constexpr int kCtlError = 4;
 // tile sizes (cells) and LDS capacities (particles staged per region)
-constexpr int kTileMain = 32, kCapMain = 1152;
+constexpr int kTileMain = 32, kCapMain = 960;
 constexpr int kTileMid = 16, kCapMid = 1920;
 constexpr int kTileSmall = 8, kCapSmall = 2048;
 constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows above this population
@@ -46,7 +71,7 @@ constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows abov
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
 // (home_cell_ids.wgsl:24-31 computes the same key; the particle id is implicit in the first pass.)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNatThreads) void k_native_hash(const float2 *__restrict__ pos, uint64_t n,
+__global__ __launch_bounds__(kStreamBlock) void k_native_hash(const float2 *__restrict__ pos, uint64_t n,
                                                               float cell_size, int32_t gx, int32_t gy,
                                                               uint32_t *__restrict__ keys,
                                                               uint32_t *__restrict__ hist4,
@@ -84,7 +109,7 @@ __global__ __launch_bounds__(kNatThreads) void k_native_hash(const float2 *__res
 
 // Largest particle count of any 3x3-block (24x24-cell) window: what the smallest cell window must hold.
 // Configuration-time check over the whole table (the step path gets the same number from the tiles).
-__global__ __launch_bounds__(kNatThreads) void k_native_window_max(const uint2 *__restrict__ table,
+__global__ __launch_bounds__(kStreamBlock) void k_native_window_max(const uint2 *__restrict__ table,
                                                                     uint32_t entries, int32_t gx, int32_t gy,
                                                                     uint32_t *__restrict__ out_max)
 {
@@ -108,7 +133,7 @@ __global__ __launch_bounds__(kNatThreads) void k_native_window_max(const uint2 *
 }
 
 // every particle inside the cell box?  (configuration-time check, not on the step path)
-__global__ __launch_bounds__(kNatThreads) void k_native_check_box(const float2 *__restrict__ pos, uint64_t n,
+__global__ __launch_bounds__(kStreamBlock) void k_native_check_box(const float2 *__restrict__ pos, uint64_t n,
                                                                    float cell_size, int32_t gx, int32_t gy,
                                                                    uint32_t *__restrict__ flag)
 {
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(kNatThreads) void k_native_check_box(const float2 *
 // table: block b = key >> 6 (an aligned 8x8-cell block is contiguous in Morton order).
 // table[b] = (first, one-past-last) position of the block's particles; empty blocks stay (0,0).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNatThreads) void k_native_block_table(const uint32_t *__restrict__ sorted_keys,
+__global__ __launch_bounds__(kStreamBlock) void k_native_block_table(const uint32_t *__restrict__ sorted_keys,
                                                                      uint64_t n, uint2 *__restrict__ table,
                                                                      uint32_t entries)
 {
@@ -187,22 +212,24 @@ struct TileLds {
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
     static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads;    // particles per thread
+    static constexpr int QZ = (T + 8) * (T + 8) / 4;                      // cells of one colour inside its zone
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
     uint32_t hm[CAP];          // bits 0-15 local index of the home cell; bits 16-27 phantom-cell codes
                                // (3 x 4 bit, (dy+1)*3+(dx+1)); bits 28-29 number of phantom cells
-    uint8_t sblk[CAP];         // region block a staged slot came from
+    // cell[lc + 1]: members of cell lc (P1) -> first slot of its list (P2) -> one past its last slot (P3);
+    // cell[0] = 0, so from P3 on the list of cell lc is mem[cell[lc] .. cell[lc + 1])
+    uint32_t cell[NCELL + 1];
     union {
-        uint32_t cnt[NCELL];   // P1-P3: members per cell, then fill cursor counting down to 0
-        uint16_t list[NCELL];  // P4-P5: active cells, four colour segments of NCELL/4
+        uint16_t mem[4 * CAP]; // member lists (local particle slots)
+        uint8_t sblk[CAP];     // P0-P1 only: region block a staged slot came from
     };
-    uint16_t cstart[NCELL + 2];
-    uint16_t mem[4 * CAP];     // member lists (local particle slots)
+    uint16_t list[4 * QZ];     // active cells, one segment per colour
     uint32_t lcnt[4];
     uint32_t bstart[NBLK];
     uint32_t bcnt[NBLK];
     uint32_t boff[NBLK + 1];
-    uint32_t s_w[4];
+    uint32_t s_w[16];
     uint32_t misc[4];
 };
 
@@ -297,7 +324,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     GPE_STAMP_BEGIN();
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
-    for (int i = tid; i < NCELL; i += kNatThreads) S.cnt[i] = 0;
+    for (int i = tid; i <= NCELL; i += kNatThreads) S.cell[i] = 0;
     if (tid < 4) S.lcnt[tid] = 0;
     if (tid < NBLK) {
         const int bi = tid % NB, bj = tid / NB;
@@ -402,7 +429,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
             }
             S.px[s] = p.x; S.py[s] = p.y; S.rad[s] = r; S.id[s] = pid[q];
             const int home = ly * RW + lx;
-            atomicAdd(&S.cnt[home], 1u);
+            atomicAdd(&S.cell[home + 1], 1u);
             // phantom cells in the reference's scan order (grid.wgsl:68-90), at most three kept.
             // is_obj_in_cell (grid.wgsl:117-129) per axis: the clamped offset of neighbour column i /
             // row j does not depend on the other axis, so the 8 tests share 3 + 3 squared offsets
@@ -428,7 +455,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
                             code |= (uint32_t)((y + 1) * 3 + (x + 1)) << (4 * pc);
                             const int nlx = lx + x, nly = ly + y;
                             if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW)
-                                atomicAdd(&S.cnt[nly * RW + nlx], 1u);
+                                atomicAdd(&S.cell[nly * RW + nlx + 1], 1u);
                         }
                         ++pc;
                     }
@@ -443,16 +470,14 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     // ---- P2: exclusive scan of the per-cell counts -> list starts ----------------------------------
     {
         const int c0 = tid * PER;
+        uint32_t cn[PER];
         uint32_t sum = 0;
 #pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (c0 + k < NCELL) sum += S.cnt[c0 + k];
-        uint32_t total = 0;
-        uint32_t run = block256_exclusive_scan(sum, S.s_w, &total);
+        for (int k = 0; k < PER; ++k) { cn[k] = (c0 + k < NCELL) ? S.cell[c0 + k + 1] : 0u; sum += cn[k]; }
+        uint32_t run = nat_block_exclusive_scan(sum, S.s_w, nullptr);
 #pragma unroll
         for (int k = 0; k < PER; ++k)
-            if (c0 + k < NCELL) { S.cstart[c0 + k] = (uint16_t)run; run += S.cnt[c0 + k]; }
-        if (tid == 0) S.cstart[NCELL] = (uint16_t)total;
+            if (c0 + k < NCELL) { S.cell[c0 + k + 1] = run; run += cn[k]; }
     }
     __syncthreads();
     GPE_STAMP(2);
@@ -461,8 +486,8 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     for (uint32_t s = tid; s < P; s += kNatThreads) {
         const uint32_t hm = S.hm[s];
         const int home = (int)(hm & 0xFFFFu);
-        uint32_t k = atomicSub(&S.cnt[home], 1u) - 1u;
-        S.mem[S.cstart[home] + k] = (uint16_t)s;
+        uint32_t k = atomicAdd(&S.cell[home + 1], 1u);
+        S.mem[k] = (uint16_t)s;
         const uint32_t pc = hm >> 28;
         const int lx = home % RW, ly = home / RW;
         for (uint32_t q = 0; q < pc; ++q) {
@@ -470,18 +495,18 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
             const int nlx = lx + (nb % 3) - 1, nly = ly + (nb / 3) - 1;
             if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) {
                 const int lc = nly * RW + nlx;
-                k = atomicSub(&S.cnt[lc], 1u) - 1u;
-                S.mem[S.cstart[lc] + k] = (uint16_t)s;
+                k = atomicAdd(&S.cell[lc + 1], 1u);
+                S.mem[k] = (uint16_t)s;
             }
         }
     }
-    __syncthreads();          // cnt is all zero again and dead from here on: `list` takes its storage
+    __syncthreads();
     GPE_STAMP(3);
 
     // ---- P4: active cells per colour.  Colour-major walk: every wave round looks at 64 cells of ONE
     //          colour, so one ballot and one LDS atomic per round compact them ---------------------------
     {
-        constexpr int HW = RW / 2, QC = NCELL / 4;                     // cells of one colour: HW x HW
+        constexpr int HW = RW / 2, QC = NCELL / 4, QZ = L::QZ;        // cells of one colour: HW x HW
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox, oy are even
@@ -493,7 +518,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
                 if (i < QC) {
                     const int lx = 2 * (i % HW) + px0, ly = 2 * (i / HW) + py0;
                     lc = ly * RW + lx;
-                    const uint32_t b = S.cstart[lc], e = S.cstart[lc + 1];
+                    const uint32_t b = S.cell[lc], e = S.cell[lc + 1];
                     const int gxx = ox + lx, gyy = oy + ly;
                     const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
                     const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
@@ -508,7 +533,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
                 uint32_t basei = 0;
                 if (lane == leader) basei = atomicAdd(&S.lcnt[c], (uint32_t)__popcll(m));
                 basei = __shfl(basei, leader, 64);
-                if (act) S.list[c * QC + basei + popc_below_lane(m)] = (uint16_t)lc;
+                if (act) S.list[c * QZ + basei + popc_below_lane(m)] = (uint16_t)lc;
             }
         }
     }
@@ -520,8 +545,8 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     for (int k = 0; k < 4; ++k) {
         const uint32_t nk = S.lcnt[k];
         for (uint32_t i = tid; i < nk; i += kNatThreads) {
-            const int lc = S.list[k * (NCELL / 4) + i];
-            const uint32_t b = S.cstart[lc], e = S.cstart[lc + 1];
+            const int lc = S.list[k * L::QZ + i];
+            const uint32_t b = S.cell[lc], e = S.cell[lc + 1];
             sort_members(S, b, e);
             resolve_cell(S, b, e, A.stiffness);
         }
@@ -644,7 +669,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     GPE_TRY(onesweep_zero_hist(c));
     {
         Scope s(c, "native/hash");
-        hipLaunchKernelGGL(k_native_hash, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, c->pos, n,
+        hipLaunchKernelGGL(k_native_hash, dim3(stream_grid(n)), dim3(kStreamBlock), 0, c->stream, c->pos, n,
                            c->cell_size, N.gx, N.gy, N.keys, c->os_ws.hist4, N.tile_ctl);
         GPE_HIP(c, hipGetLastError());
     }
@@ -655,7 +680,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     }
     {
         Scope s(c, "native/table");
-        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid(n)), dim3(kNatThreads), 0, c->stream, sk, n,
+        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid(n)), dim3(kStreamBlock), 0, c->stream, sk, n,
                            N.block_table, N.table_entries);
         GPE_HIP(c, hipGetLastError());
     }
@@ -715,7 +740,7 @@ gpe_status native_configure(gpe_ctx *c)
     N.host_stat[0] = 0;
     GPE_TRY(onesweep_reserve(c, c->cap));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
-    hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kNatThreads), 0, c->stream, c->pos, c->n,
+    hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kStreamBlock), 0, c->stream, c->pos, c->n,
                        c->cell_size, N.gx, N.gy, N.tile_ctl + kCtlError);
     GPE_HIP(c, hipGetLastError());
     uint32_t flag = 1;
@@ -730,7 +755,7 @@ gpe_status native_configure(gpe_ctx *c)
     gpe_status st = native_prepare_step(c, &ids);
     c->profiling = prof;
     GPE_TRY(st);
-    hipLaunchKernelGGL(k_native_window_max, dim3(stream_grid(N.table_entries)), dim3(kNatThreads), 0, c->stream,
+    hipLaunchKernelGGL(k_native_window_max, dim3(stream_grid(N.table_entries)), dim3(kStreamBlock), 0, c->stream,
                        N.block_table, N.table_entries, N.gx, N.gy, N.tile_ctl + kCtlWindowMax);
     GPE_HIP(c, hipGetLastError());
     uint32_t wmax = 0xffffffffu;
