@@ -24,7 +24,7 @@ COUNTING_CHUNK_SIZE = 4
 
 # gpe_array
 POS, PREV, RADIUS, HOME_CELL_IDS, PARTICLE_IDS, CELL_IDS, OBJECT_IDS, COLLISION_CELLS, \
-    NUM_COLLISION_CELLS, CHUNK_OBJ_COUNT, INDIRECT_ARGS = range(11)
+    NUM_COLLISION_CELLS, CHUNK_OBJ_COUNT, INDIRECT_ARGS, ORDER_KEYS = range(12)
 
 
 class GpeConfig(C.Structure):
@@ -88,6 +88,14 @@ SYMBOLS = [
     ("gpe_sort_histogram_u32", _I32, [_VP, _VP, _U64, _U32, _VP]),
     ("gpe_sort_scatter_pass_u32", _I32, [_VP, _VP, _VP, _VP, _VP, _U64, _U32]),
     ("gpe_inclusive_scan_u32", _I32, [_VP, _VP, _U64]),
+    ("gpe_reserve", _I32, [_VP, _U64]),
+    ("gpe_capacity", _I32, [_VP, C.POINTER(_U64)]),
+    ("gpe_set_counts", _I32, [_VP, _U64, _U64]),
+    ("gpe_use_order_keys", _I32, [_VP, _I32]),
+    ("gpe_set_active_cells", _I32, [_VP, _I32, _I32, _I32, _I32]),
+    ("gpe_stream_handle", _I32, [_VP, C.POINTER(_VP)]),
+    ("gpe_refresh", _I32, [_VP]),
+    ("gpe_shard_classify", _I32, [_VP, _VP, _VP, _I32, _I32, _U32, _VP, _VP, _VP, _U64]),
     ("gpe_set_profiling", _I32, [_VP, _U32]),
     ("gpe_reset_timings", _I32, [_VP]),
     ("gpe_get_timings", _I32, [_VP, C.POINTER(GpeTiming), C.POINTER(_U32)]),

@@ -105,6 +105,7 @@ static void free_particle_buffers(gpe_ctx *c)
     dev_free(c->home_cell_ids); dev_free(c->particle_ids);
     dev_free(c->cell_ids); dev_free(c->object_ids);
     dev_free(c->chunk_obj_count); dev_free(c->collision_cells); dev_free(c->indirect_args);
+    dev_free(c->order_keys);
     c->cap = 0;
 }
 
@@ -150,6 +151,7 @@ static gpe_status alloc_particle_buffers(gpe_ctx *c, uint64_t cap)
     GPE_TRY(dev_alloc(c, &c->chunk_obj_count, cap));
     GPE_TRY(dev_alloc(c, &c->collision_cells, cap * 4));
     GPE_TRY(dev_alloc(c, &c->indirect_args, 4));
+    GPE_TRY(dev_alloc(c, &c->order_keys, cap));
     c->cap = cap;
     GPE_TRY(sort_reserve(c, cap * 4));
     GPE_TRY(scan_reserve(c, cap));
@@ -169,6 +171,47 @@ static gpe_status init_index_buffers(gpe_ctx *c, uint64_t lo, uint64_t hi)
     GPE_TRY(fill_u32(c, c->object_ids + 4 * lo, 4 * cnt, 0u));              // grid.rs:85-89
     GPE_TRY(fill_u32(c, c->collision_cells + 4 * lo, 4 * cnt, kUnused));    // collision_cell_buffers.rs:23-27
     GPE_TRY(fill_u32(c, c->chunk_obj_count + lo, cnt, 0u));                 // collision_cell_buffers.rs:17-21
+    return GPE_OK;
+}
+
+// Reallocate every particle-count-dependent buffer for `cap` particles, keeping the contents of the
+// first c->n (GpuBuffer::push grows x2 with a device copy, utils/gpu_buffer.rs:49-87).  Synchronises.
+static gpe_status grow_particle_buffers(gpe_ctx *c, uint64_t cap)
+{
+    struct Old {
+        float2 *pos, *prev, *pos_copy, *prev_copy;
+        float *radius, *radius_copy;
+        uint32_t *home_cell_ids, *particle_ids, *cell_ids, *object_ids, *chunk_obj_count, *collision_cells,
+            *indirect_args, *order_keys;
+    } old = {c->pos, c->prev, c->pos_copy, c->prev_copy, c->radius, c->radius_copy, c->home_cell_ids,
+             c->particle_ids, c->cell_ids, c->object_ids, c->chunk_obj_count, c->collision_cells,
+             c->indirect_args, c->order_keys};
+    const uint64_t old_n = c->n;
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    c->pos = c->prev = c->pos_copy = c->prev_copy = nullptr;
+    c->radius = c->radius_copy = nullptr;
+    c->home_cell_ids = c->particle_ids = c->cell_ids = c->object_ids = nullptr;
+    c->chunk_obj_count = c->collision_cells = c->indirect_args = c->order_keys = nullptr;
+    GPE_TRY(alloc_particle_buffers(c, cap));
+    if (old.pos && old_n) {
+#define GPE_COPY_OLD(field, count)                                                                     \
+        GPE_HIP(c, hipMemcpyAsync(c->field, old.field, (count) * sizeof(*c->field), hipMemcpyDeviceToDevice, c->stream))
+        GPE_COPY_OLD(pos, old_n); GPE_COPY_OLD(prev, old_n); GPE_COPY_OLD(radius, old_n);
+        GPE_COPY_OLD(home_cell_ids, old_n); GPE_COPY_OLD(particle_ids, old_n);
+        GPE_COPY_OLD(cell_ids, 4 * old_n); GPE_COPY_OLD(object_ids, 4 * old_n);
+        GPE_COPY_OLD(chunk_obj_count, old_n); GPE_COPY_OLD(collision_cells, 4 * old_n);
+        GPE_COPY_OLD(indirect_args, 3);
+        if (old.order_keys) GPE_COPY_OLD(order_keys, old_n);
+#undef GPE_COPY_OLD
+    }
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    float2 *fp[] = {old.pos, old.prev, old.pos_copy, old.prev_copy};
+    for (float2 *p : fp) if (p) (void)hipFree(p);
+    float *ff[] = {old.radius, old.radius_copy};
+    for (float *p : ff) if (p) (void)hipFree(p);
+    uint32_t *fu[] = {old.home_cell_ids, old.particle_ids, old.cell_ids, old.object_ids, old.chunk_obj_count,
+                      old.collision_cells, old.indirect_args, old.order_keys};
+    for (uint32_t *p : fu) if (p) (void)hipFree(p);
     return GPE_OK;
 }
 
@@ -243,12 +286,17 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
 {
     // state.rs:115-131
     if (flags & GPE_STEP_RESORT) GPE_TRY(do_resort(c));                          // :122-125
-    if (native_should_run(c)) {
+    const bool native = native_should_run(c);
+    if (c->use_order_keys && !native)
+        return fail(c, GPE_ERR_UNSUPPORTED,
+                    "order keys (sharded run) need the native pipeline: mode NATIVE, particles inside the world "
+                    "box, bounded density");
+    if (native) {
         // grid update + collision solve as N-key sort + LDS cell windows (k_native.hip); the resolved
         // positions land in the scratch set, which then becomes the live one
         GPE_TRY(native_collide(c, c->pos, c->pos_copy));
         std::swap(c->pos, c->pos_copy);
-        GPE_TRY(launch_verlet(c, c->pos, c->prev, c->radius, c->n, dt));         // :130
+        GPE_TRY(launch_verlet(c, c->pos, c->prev, c->radius, c->n_owned, dt));   // :130
         return GPE_OK;
     }
     GPE_TRY(launch_build_cell_ids(c, c->pos, c->radius, c->n, c->cell_size, c->cell_ids,
@@ -256,7 +304,7 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
     GPE_TRY(do_grid_sort(c));
     GPE_TRY(do_build_collision_cells(c));                                        // :127
     GPE_TRY(do_solve_colors(c));
-    GPE_TRY(launch_verlet(c, c->pos, c->prev, c->radius, c->n, dt));             // :130
+    GPE_TRY(launch_verlet(c, c->pos, c->prev, c->radius, c->n_owned, dt));       // :130
     return GPE_OK;
 }
 
@@ -412,6 +460,7 @@ gpe_status gpe_set_particles(gpe_ctx *c, const float *pos_xy, const float *prev_
         if (s != GPE_OK) { free_particle_buffers(c); c->n = 0; return s; }
     }
     c->n = n;
+    c->n_owned = n;
     GPE_HIP(c, hipMemcpyAsync(c->pos, pos_xy, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     GPE_HIP(c, hipMemcpyAsync(c->prev, prev_xy ? prev_xy : pos_xy, n * sizeof(float2), hipMemcpyHostToDevice,
                               c->stream));
@@ -433,38 +482,12 @@ gpe_status gpe_add_particles(gpe_ctx *c, const float *pos_xy, const float *radiu
     if (new_n > (1ull << 30) - 1) return fail(c, GPE_ERR_INVALID_ARG, "gpe_add_particles: 4n must fit in u32");
     GPE_HIP(c, hipSetDevice(c->device));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
-    if (new_n > c->cap) {
-        // GpuBuffer::push grows x2 with a device copy (utils/gpu_buffer.rs:49-87)
-        gpe_ctx old = *c;   // shallow copy of the pointers
-        uint64_t cap = std::max<uint64_t>(new_n, old.cap * 2);
-        c->pos = c->prev = c->pos_copy = c->prev_copy = nullptr;
-        c->radius = c->radius_copy = nullptr;
-        c->home_cell_ids = c->particle_ids = c->cell_ids = c->object_ids = nullptr;
-        c->chunk_obj_count = c->collision_cells = c->indirect_args = nullptr;
-        gpe_status s = alloc_particle_buffers(c, cap);
-        if (s != GPE_OK) return s;
-#define GPE_COPY_OLD(field, count)                                                                     \
-        GPE_HIP(c, hipMemcpyAsync(c->field, old.field, (count) * sizeof(*c->field), hipMemcpyDeviceToDevice, c->stream))
-        GPE_COPY_OLD(pos, old_n); GPE_COPY_OLD(prev, old_n); GPE_COPY_OLD(radius, old_n);
-        GPE_COPY_OLD(home_cell_ids, old_n); GPE_COPY_OLD(particle_ids, old_n);
-        GPE_COPY_OLD(cell_ids, 4 * old_n); GPE_COPY_OLD(object_ids, 4 * old_n);
-        GPE_COPY_OLD(chunk_obj_count, old_n); GPE_COPY_OLD(collision_cells, 4 * old_n);
-        GPE_COPY_OLD(indirect_args, 3);
-#undef GPE_COPY_OLD
-        GPE_HIP(c, hipStreamSynchronize(c->stream));
-        float2 *fp[] = {old.pos, old.prev, old.pos_copy, old.prev_copy};
-        for (float2 *p : fp) if (p) (void)hipFree(p);
-        float *ff[] = {old.radius, old.radius_copy};
-        for (float *p : ff) if (p) (void)hipFree(p);
-        uint32_t *fu[] = {old.home_cell_ids, old.particle_ids, old.cell_ids, old.object_ids,
-                          old.chunk_obj_count, old.collision_cells, old.indirect_args};
-        for (uint32_t *p : fu) if (p) (void)hipFree(p);
-        // `old` shares the std:: members by value copy only; nothing else to release
-    }
+    if (new_n > c->cap) GPE_TRY(grow_particle_buffers(c, std::max<uint64_t>(new_n, c->cap * 2)));
     GPE_HIP(c, hipMemcpyAsync(c->pos + old_n, pos_xy, n_add * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     GPE_HIP(c, hipMemcpyAsync(c->prev + old_n, pos_xy, n_add * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     GPE_HIP(c, hipMemcpyAsync(c->radius + old_n, radius, n_add * sizeof(float), hipMemcpyHostToDevice, c->stream));
     c->n = new_n;
+    c->n_owned = new_n;
     GPE_TRY(init_index_buffers(c, old_n, new_n));
     // particle_system.rs:198: max_radius = max(max_radius, r)
     for (uint64_t i = 0; i < n_add; ++i) c->max_radius = fmaxf(c->max_radius, radius[i]);
@@ -524,7 +547,7 @@ gpe_status gpe_integrate(gpe_ctx *c, float dt)
 {
     GPE_TRY(need_particles(c));
     GPE_HIP(c, hipSetDevice(c->device));
-    return launch_verlet(c, c->pos, c->prev, c->radius, c->n, dt);
+    return launch_verlet(c, c->pos, c->prev, c->radius, c->n_owned, dt);
 }
 
 // ---- grid ---------------------------------------------------------------------------------------------
@@ -630,6 +653,7 @@ static gpe_status locate(gpe_ctx *c, gpe_array what, const void **ptr, uint64_t 
             break;
         case GPE_CHUNK_OBJ_COUNT: *ptr = c->chunk_obj_count; *bytes = num_chunks(c) * 4; break;
         case GPE_INDIRECT_ARGS: *ptr = c->indirect_args; *bytes = 12; break;
+        case GPE_ORDER_KEYS: *ptr = c->order_keys; *bytes = n * 4; break;
         default: return fail(c, GPE_ERR_INVALID_ARG, "unknown gpe_array");
     }
     return GPE_OK;
@@ -746,6 +770,79 @@ gpe_status gpe_inclusive_scan_u32(gpe_ctx *c, uint32_t *d_data, uint64_t n)
     GPE_HIP(c, hipSetDevice(c->device));
     GPE_TRY(scan_reserve(c, n));
     return inclusive_scan(c, d_data, n);
+}
+
+// ---- sharding support -------------------------------------------------------------------------------------
+gpe_status gpe_reserve(gpe_ctx *c, uint64_t capacity)
+{
+    GPE_TRY(need_particles(c));
+    if (capacity > (1ull << 30) - 1) return fail(c, GPE_ERR_INVALID_ARG, "gpe_reserve: 4n must fit in u32");
+    GPE_HIP(c, hipSetDevice(c->device));
+    if (capacity > c->cap) {
+        GPE_TRY(grow_particle_buffers(c, capacity));
+        GPE_TRY(reconfigure(c));
+    }
+    return GPE_OK;
+}
+
+gpe_status gpe_capacity(const gpe_ctx *c, uint64_t *capacity)
+{
+    if (!c || !capacity) return GPE_ERR_INVALID_ARG;
+    *capacity = c->cap;
+    return GPE_OK;
+}
+
+gpe_status gpe_set_counts(gpe_ctx *c, uint64_t n_total, uint64_t n_owned)
+{
+    GPE_TRY(need_particles(c));
+    if (n_total == 0 || n_total > c->cap || n_owned > n_total)
+        return fail(c, GPE_ERR_INVALID_ARG, "gpe_set_counts: need 0 < n_owned <= n_total <= capacity");
+    c->n = n_total;
+    c->n_owned = n_owned;
+    return GPE_OK;
+}
+
+gpe_status gpe_use_order_keys(gpe_ctx *c, int32_t enable)
+{
+    if (!c) return GPE_ERR_INVALID_ARG;
+    c->use_order_keys = enable != 0;
+    return GPE_OK;
+}
+
+gpe_status gpe_set_active_cells(gpe_ctx *c, int32_t cx0, int32_t cy0, int32_t cx1, int32_t cy1)
+{
+    if (!c) return GPE_ERR_INVALID_ARG;
+    if (cx1 < cx0 || cy1 < cy0) return fail(c, GPE_ERR_INVALID_ARG, "gpe_set_active_cells: empty box");
+    c->active_box[0] = cx0; c->active_box[1] = cy0; c->active_box[2] = cx1; c->active_box[3] = cy1;
+    c->has_active_box = true;
+    return GPE_OK;
+}
+
+gpe_status gpe_stream_handle(gpe_ctx *c, void **hip_stream)
+{
+    if (!c || !hip_stream) return GPE_ERR_INVALID_ARG;
+    *hip_stream = (void *)c->stream;
+    return GPE_OK;
+}
+
+gpe_status gpe_refresh(gpe_ctx *c)
+{
+    GPE_TRY(need_particles(c));
+    GPE_HIP(c, hipSetDevice(c->device));
+    return reconfigure(c);
+}
+
+gpe_status gpe_shard_classify(gpe_ctx *c, const uint8_t *d_owner_of_block, const uint32_t *d_dest_mask_of_block,
+                              int32_t blocks_x, int32_t blocks_y, uint32_t my_rank, uint32_t *d_out_index,
+                              uint32_t *d_out_info, uint32_t *d_out_count, uint64_t out_capacity)
+{
+    GPE_TRY(need_particles(c));
+    if (!d_owner_of_block || !d_dest_mask_of_block || !d_out_index || !d_out_info || !d_out_count || blocks_x <= 0 ||
+        blocks_y <= 0)
+        return fail(c, GPE_ERR_INVALID_ARG, "gpe_shard_classify: bad argument");
+    GPE_HIP(c, hipSetDevice(c->device));
+    return launch_shard_classify(c, d_owner_of_block, d_dest_mask_of_block, blocks_x, blocks_y, my_rank, d_out_index,
+                                 d_out_info, d_out_count, out_capacity);
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------------

@@ -215,7 +215,8 @@ struct gpe_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
 
-    uint64_t n = 0;          // particles
+    uint64_t n = 0;          // particles taking part in collisions (owned + ghosts in a sharded run)
+    uint64_t n_owned = 0;    // the first n_owned are integrated by K12 (== n unless sharded)
     uint64_t cap = 0;        // allocated particle capacity
     float max_radius = 0.f;  // ParticleSystem::max_radius
     float grid_max_radius = 0.f;
@@ -235,6 +236,11 @@ struct gpe_ctx {
     uint32_t *chunk_obj_count = nullptr;   // ceil(4n/4) = n entries
     uint32_t *collision_cells = nullptr;   // 4n entries
     uint32_t *indirect_args = nullptr;     // 3 entries (+1: K)
+    // sharded runs: global object index of every local particle (in-cell order), active cell box
+    uint32_t *order_keys = nullptr;
+    bool use_order_keys = false;
+    bool has_active_box = false;
+    int32_t active_box[4] = {0, 0, 0, 0};   // cx0, cy0, cx1, cy1 (inclusive) holding this rank's particles
 
     gpe::SortWorkspace sort_ws;
     gpe::ScanWorkspace scan_ws;
@@ -311,6 +317,9 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
 // native pipeline (k_native.hip)
 gpe_status native_configure(gpe_ctx *c);
 bool native_should_run(gpe_ctx *c);
+gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, const uint32_t *dest_mask_of_block,
+                                 int32_t blocks_x, int32_t blocks_y, uint32_t my_rank, uint32_t *out_index,
+                                 uint32_t *out_info, uint32_t *out_count, uint64_t out_capacity);
 void native_release(gpe_ctx *c);
 gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out);
 // collision cells + solver

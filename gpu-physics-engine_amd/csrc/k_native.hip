@@ -22,6 +22,8 @@
 // read a tile's step-start positions while it writes its results.
 #include <stdio.h>
 
+#include <algorithm>
+
 #include "gpe_internal.h"
 
 #ifndef GPE_NAT_THREADS
@@ -179,7 +181,9 @@ struct CollideArgs {
     float cell_size;
     float stiffness;
     int32_t gx, gy;              // cell box
-    int32_t tiles_x, tiles_y;    // tile grid of THIS kernel's tile size
+    int32_t tiles_x, tiles_y;    // tile grid of the dense launch
+    int32_t tile_x0, tile_y0;    // its first tile (sharded runs cut the grid to the rank's active box)
+    const uint32_t *order_keys;  // sharded runs: in-cell order by order_keys[local index]; else NULL
     uint32_t *tile_ctl;          // kCtl* words
     uint32_t *overflow1;         // packed (ty << 16 | tx) of over-capacity 32x32 tiles
     uint32_t overflow1_cap;
@@ -408,7 +412,13 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
             const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
             pp[q] = make_float2(0.f, 0.f);
             pr[q] = 0.f;
-            if (s < P) { pp[q] = A.pos_in[pid[q]]; pr[q] = A.radius[pid[q]]; }
+            if (s < P) {
+                pp[q] = A.pos_in[pid[q]];
+                pr[q] = A.radius[pid[q]];
+                // sharded run: the member order is the particle's index in the unsharded system; the local
+                // index is looked up again at write-back (P6)
+                if (A.order_keys) pid[q] = A.order_keys[pid[q]];
+            }
         }
 #ifdef GPE_TILE_STAMPS
         { float acc = 0; for (int q = 0; q < QMAX; ++q) acc += pp[q].x + pr[q]; asm volatile("" :: "v"(acc)); }
@@ -561,8 +571,18 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     for (uint32_t s = tid; s < P; s += kNatThreads) {
         const int home = (int)(S.hm[s] & 0xFFFFu);
         const int lx = home % RW, ly = home / RW;
-        if (lx >= kHalo && lx < kHalo + T && ly >= kHalo && ly < kHalo + T)
-            A.pos_out[S.id[s]] = make_float2(S.px[s], S.py[s]);
+        if (lx >= kHalo && lx < kHalo + T && ly >= kHalo && ly < kHalo + T) {
+            uint32_t id = S.id[s];
+            if (A.order_keys) {                                        // S.id holds the order key: find the
+                int lo = 0, hi = NBLK;                                 // slot's block, re-read the local index
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (S.boff[mid] <= s) lo = mid; else hi = mid;
+                }
+                id = A.sorted_ids[S.bstart[lo] + (s - S.boff[lo])];
+            }
+            A.pos_out[id] = make_float2(S.px[s], S.py[s]);
+        }
     }
     __syncthreads();
     GPE_STAMP(6);
@@ -580,7 +600,7 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     const uint32_t per_xcd = (total + 7u) / 8u;
     const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
-    const int tx = (int)(t % (uint32_t)A.tiles_x), ty = (int)(t / (uint32_t)A.tiles_x);
+    const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
     if (!process_tile<T, CAP>(S, A, tx, ty)) {
         if (threadIdx.x == 0) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
@@ -814,6 +834,8 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     A.overflow1_cap = (uint32_t)N.overflow_cap;
     A.overflow2 = N.overflow2;
     A.overflow2_cap = (uint32_t)(4 * N.overflow_cap);
+    A.order_keys = c->use_order_keys ? c->order_keys : nullptr;
+    A.tile_x0 = A.tile_y0 = 0;
     A.stamps = nullptr;
 #ifdef GPE_TILE_STAMPS
     static unsigned long long *g_stamps = nullptr;
@@ -832,8 +854,16 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
 #endif
     {
         Scope s(c, "native/collide");
-        A.tiles_x = (N.gx + kTileMain - 1) / kTileMain;
-        A.tiles_y = (N.gy + kTileMain - 1) / kTileMain;
+        int32_t cx0 = 0, cy0 = 0, cx1 = N.gx - 1, cy1 = N.gy - 1;
+        if (c->has_active_box) {                                       // sharded: only this rank's cells
+            cx0 = std::max(cx0, c->active_box[0]); cy0 = std::max(cy0, c->active_box[1]);
+            cx1 = std::min(cx1, c->active_box[2]); cy1 = std::min(cy1, c->active_box[3]);
+            if (cx1 < cx0 || cy1 < cy0) { cx1 = cx0; cy1 = cy0; }
+        }
+        A.tile_x0 = cx0 / kTileMain;
+        A.tile_y0 = cy0 / kTileMain;
+        A.tiles_x = cx1 / kTileMain - A.tile_x0 + 1;
+        A.tiles_y = cy1 / kTileMain - A.tile_y0 + 1;
         const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
         const uint32_t grid = ((total + 7u) / 8u) * 8u;
         hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
@@ -850,6 +880,63 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     }
     GPE_HIP(c, hipMemcpyAsync(N.host_stat, N.tile_ctl + kCtlWindowMax, sizeof(uint32_t), hipMemcpyDeviceToHost,
                               c->stream));
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sharded runs: which owned particles must travel (gpe_shard_classify)
+// ---------------------------------------------------------------------------------------------------
+// One streaming pass over the owned particles: R pos 8 B + one table byte/word per particle.  The few
+// that sit in a block owned by another rank (migrants) or bordering other ranks (ghost candidates) are
+// appended with one global atomic per wave.
+__global__ __launch_bounds__(kStreamBlock) void k_shard_classify(const float2 *__restrict__ pos, uint64_t n_owned,
+                                                                  float cell_size,
+                                                                  const uint8_t *__restrict__ owner_of_block,
+                                                                  const uint32_t *__restrict__ dest_mask_of_block,
+                                                                  int32_t blocks_x, int32_t blocks_y, uint32_t my_rank,
+                                                                  uint32_t *__restrict__ out_index,
+                                                                  uint32_t *__restrict__ out_info,
+                                                                  uint32_t *__restrict__ out_count, uint64_t out_capacity)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n_owned + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t info = 0;
+        if (i < n_owned) {
+            const float2 p = pos[i];
+            int bx = cell_coord(p.x, cell_size) >> 3, by = cell_coord(p.y, cell_size) >> 3;
+            bx = min(max(bx, 0), blocks_x - 1);
+            by = min(max(by, 0), blocks_y - 1);
+            const uint32_t b = (uint32_t)by * (uint32_t)blocks_x + (uint32_t)bx;
+            const uint32_t owner = owner_of_block[b];
+            // bits 0-25: ranks bordering the block the particle sits in NOW (they need it as a ghost);
+            // bits 26-30: 1 + owner of that block when it is not this rank (the particle migrates)
+            info = (dest_mask_of_block[b] & 0x03FFFFFFu) | ((owner != my_rank) ? ((owner + 1u) << 26) : 0u);
+        }
+        const uint64_t m = __ballot(info != 0);
+        if (m == 0) continue;
+        const int leader = (int)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane_id() == leader) base = atomicAdd(out_count, (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (info != 0) {
+            const uint64_t slot = (uint64_t)base + popc_below_lane(m);
+            if (slot < out_capacity) { out_index[slot] = (uint32_t)i; out_info[slot] = info; }
+        }
+    }
+}
+
+gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, const uint32_t *dest_mask_of_block,
+                                 int32_t blocks_x, int32_t blocks_y, uint32_t my_rank, uint32_t *out_index,
+                                 uint32_t *out_info, uint32_t *out_count, uint64_t out_capacity)
+{
+    if (c->n_owned == 0) return GPE_OK;
+    Scope s(c, "shard/classify");
+    hipLaunchKernelGGL(k_shard_classify, dim3(stream_grid(c->n_owned)), dim3(kStreamBlock), 0, c->stream, c->pos,
+                       c->n_owned, c->cell_size, owner_of_block, dest_mask_of_block, blocks_x, blocks_y, my_rank,
+                       out_index, out_info, out_count, out_capacity);
+    GPE_HIP(c, hipGetLastError());
     return GPE_OK;
 }
 

@@ -1,0 +1,418 @@
+"""Multi-GPU particle step: one process per GPU, spatial shards, point-to-point halo exchange.
+
+The reference is single-device.  Here every rank owns the particles whose HOME CELL lies in its part of the
+world (ownership is per 8x8-cell block, the granule of the library's block table).  Each step:
+
+  1. classify   one streaming pass (library kernel `gpe_shard_classify`) lists the owned particles that
+                now sit in another rank's block (migrants) or in a block bordering other ranks (ghosts);
+  2. exchange   counts by all_gather, then ONE message per neighbouring rank pair over
+                torch.distributed point-to-point (`batch_isend_irecv`; backend nccl = RCCL send/recv over
+                xGMI on GPUs, gloo on CPU): migrants travel with (pos, prev, radius, order key), ghosts
+                with (pos, radius, order key);
+  3. step       the rank runs the ordinary step on owned + ghost particles; only owned ones are
+                integrated (gpe_set_counts), ghosts are dropped afterwards.
+
+Exactness.  A ghost band of one block (8 cells) covers the dependency cone of the four colour passes
+(colour-k cells within 5-k cells of an owned particle's home, their members' homes within 5 cells), and
+the members of a cell are ordered by ORDER KEY = the particle's index in the unsharded system
+(gpe_use_order_keys), so every rank resolves its own particles with exactly the operations the
+single-device run performs: the sharded result is bit-identical (tests/test_sharded_cpu.py runs two gloo
+ranks against the single-process oracle).  The Morton re-sort assigns the new indices globally: new index =
+(particles of all ranks in Morton blocks before mine) + rank inside the block by (cell key, old index).
+
+The engine behind a rank is pluggable (`engine` argument): `GpeEngine` drives libgpe.so on the rank's GPU;
+the CPU tests plug in an oracle-backed engine (tests only) to exercise this file without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+BLOCK = 8                    # cells per ownership block edge == the library's block-table granule
+
+
+# ------------------------------------------------------------------------------------------------------
+# decomposition
+# ------------------------------------------------------------------------------------------------------
+def _factor(world_size):
+    """Px x Py process grid, as square as possible, Px <= Py."""
+    px = int(np.floor(np.sqrt(world_size)))
+    while world_size % px:
+        px -= 1
+    return px, world_size // px
+
+
+class Decomposition:
+    """Rectangles of 8x8-cell blocks: owner[block], dest_mask[block] (ranks whose region is within one block)."""
+
+    def __init__(self, world, cell_size, world_size, grid=None):
+        self.world = (float(world[0]), float(world[1]))
+        self.cell_size = np.float32(cell_size)
+        # same arithmetic as the library's native_configure: largest home coordinate = floor(world / cell)
+        self.gx = int(np.floor(np.float32(world[0]) / self.cell_size)) + 1
+        self.gy = int(np.floor(np.float32(world[1]) / self.cell_size)) + 1
+        self.bx = (self.gx + BLOCK - 1) // BLOCK
+        self.by = (self.gy + BLOCK - 1) // BLOCK
+        self.world_size = world_size
+        self.px, self.py = grid if grid is not None else _factor(world_size)
+        if self.px * self.py != world_size:
+            raise ValueError("process grid does not match world_size")
+        if world_size > 26:
+            raise ValueError("destination masks are 26 bits wide")
+        if self.px > self.bx or self.py > self.by:
+            raise ValueError("world too small for this many ranks")
+        self.xcuts = [round(i * self.bx / self.px) for i in range(self.px + 1)]
+        self.ycuts = [round(j * self.by / self.py) for j in range(self.py + 1)]
+        col = np.zeros(self.bx, np.int64)
+        row = np.zeros(self.by, np.int64)
+        for i in range(self.px):
+            col[self.xcuts[i]:self.xcuts[i + 1]] = i
+        for j in range(self.py):
+            row[self.ycuts[j]:self.ycuts[j + 1]] = j
+        owner = (row[:, None] * self.px + col[None, :]).astype(np.uint8)           # [by, bx]
+        bits = (np.uint32(1) << owner.astype(np.uint32))
+        pad = np.zeros((self.by + 2, self.bx + 2), np.uint32)
+        pad[1:-1, 1:-1] = bits
+        mask = np.zeros_like(bits)
+        for dy in range(3):
+            for dx in range(3):
+                mask |= pad[dy:dy + self.by, dx:dx + self.bx]
+        self.owner = np.ascontiguousarray(owner)
+        self.dest_mask = np.ascontiguousarray(mask & ~bits)
+
+    def rect_blocks(self, rank):
+        i, j = rank % self.px, rank // self.px
+        return self.xcuts[i], self.ycuts[j], self.xcuts[i + 1], self.ycuts[j + 1]      # half-open, blocks
+
+    def rect_units(self, rank):
+        """World-space rectangle whose particles (by home cell) this rank owns."""
+        x0, y0, x1, y1 = self.rect_blocks(rank)
+        cs = float(self.cell_size) * BLOCK
+        return x0 * cs, y0 * cs, min(x1 * cs, self.world[0]), min(y1 * cs, self.world[1])
+
+    def active_cells(self, rank):
+        """Inclusive cell box holding the rank's own blocks plus the one-block ghost ring."""
+        x0, y0, x1, y1 = self.rect_blocks(rank)
+        return (max(0, (x0 - 1) * BLOCK), max(0, (y0 - 1) * BLOCK),
+                min(self.gx - 1, (x1 + 1) * BLOCK - 1), min(self.gy - 1, (y1 + 1) * BLOCK - 1))
+
+    def owner_of(self, pos):
+        """Owner rank of host positions (numpy, same float32 arithmetic as the kernels)."""
+        pos = np.asarray(pos, np.float32).reshape(-1, 2)
+        cx = np.floor(pos[:, 0] / self.cell_size).astype(np.int64) >> 3
+        cy = np.floor(pos[:, 1] / self.cell_size).astype(np.int64) >> 3
+        cx = np.clip(cx, 0, self.bx - 1)
+        cy = np.clip(cy, 0, self.by - 1)
+        return self.owner[cy, cx].astype(np.int64)
+
+    def morton_entries(self):
+        def split(n):
+            x = n & 0xFFFF
+            x = (x | (x << 8)) & 0x00FF00FF
+            x = (x | (x << 4)) & 0x0F0F0F0F
+            x = (x | (x << 2)) & 0x33333333
+            x = (x | (x << 1)) & 0x55555555
+            return x
+        max_key = split(self.gx - 1) | (split(self.gy - 1) << 1)
+        return (max_key >> 6) + 1
+
+
+# ------------------------------------------------------------------------------------------------------
+# GPU engine (libgpe.so)
+# ------------------------------------------------------------------------------------------------------
+class _DevArray:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class GpeEngine:
+    """One rank's particles inside a gpe context (native mode, order keys on)."""
+
+    def __init__(self, pos, rad, gid, world, gravity=(0.0, 0.0), device=0, capacity=None, profiling=False):
+        from .engine import Context
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.ctx = Context(world=world, gravity=gravity, mode=L.MODE_NATIVE, device=device, profiling=profiling)
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+        rad = np.ascontiguousarray(rad, np.float32)
+        n = pos.shape[0]
+        if n == 0:
+            raise ValueError("every rank needs at least one particle at start")
+        self.ctx.call("gpe_set_particles", pos.ctypes.data_as(C.c_void_p), None, rad.ctypes.data_as(C.c_void_p), n)
+        self.ctx.call("gpe_use_order_keys", 1)
+        self.reserve(capacity or int(n * 1.3) + 4096)
+        h = C.c_void_p()
+        self.ctx.call("gpe_stream_handle", C.byref(h))
+        self.stream = torch.cuda.ExternalStream(h.value, device=self.device)
+        self.n_owned = n
+        with torch.cuda.stream(self.stream):
+            self.arrays()["gid"][:n] = torch.as_tensor(np.ascontiguousarray(gid, np.int64), device=self.device).to(torch.int32)
+        self.ctx.sync()
+
+    # -- storage ------------------------------------------------------------------------------------
+    def capacity(self):
+        cap = C.c_uint64()
+        self.ctx.call("gpe_capacity", C.byref(cap))
+        return cap.value
+
+    def reserve(self, capacity):
+        self.ctx.call("gpe_reserve", int(capacity))
+
+    def _view(self, what, shape, typestr):
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        self.ctx.call("gpe_device_ptr", what, C.byref(ptr), C.byref(nbytes))
+        return torch.as_tensor(_DevArray(ptr.value, shape, typestr), device=self.device)
+
+    def arrays(self):
+        """Views over the context's buffers at full capacity (they move at every step / reserve / resort)."""
+        cap = self.capacity()
+        return {"pos": self._view(L.POS, (cap, 2), "<f4"), "prev": self._view(L.PREV, (cap, 2), "<f4"),
+                "radius": self._view(L.RADIUS, (cap,), "<f4"), "gid": self._view(L.ORDER_KEYS, (cap,), "<i4")}
+
+    def set_counts(self, n_total, n_owned):
+        self.ctx.call("gpe_set_counts", int(n_total), int(n_owned))
+
+    # -- per step ------------------------------------------------------------------------------------
+    def classify(self, dec, rank, tables):
+        owner_t, mask_t, out_idx, out_info, out_cnt = tables
+        out_cnt.zero_()
+        self.ctx.call("gpe_shard_classify", owner_t.data_ptr(), mask_t.data_ptr(), dec.bx, dec.by, rank,
+                      out_idx.data_ptr(), out_info.data_ptr(), out_cnt.data_ptr(), out_idx.numel())
+        k = int(out_cnt[0].item())                   # the one host sync of the exchange
+        if k > out_idx.numel():
+            raise RuntimeError("shard classify overflow: %d boundary particles, capacity %d" % (k, out_idx.numel()))
+        return out_idx[:k].long(), out_info[:k]
+
+    def make_tables(self, dec, cap):
+        dev = self.device
+        return (torch.as_tensor(dec.owner.reshape(-1), device=dev), torch.as_tensor(dec.dest_mask.reshape(-1).astype(np.int32), device=dev),
+                torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                torch.zeros(4, dtype=torch.int32, device=dev))
+
+    def step(self, dt):
+        self.ctx.call("gpe_step", float(dt), 0)
+
+    def morton_resort(self):
+        """K1 + stable sort by home-cell key + K4 on the owned particles (ties keep the current order).
+        Returns (sorted keys, permutation) as int64 tensors."""
+        self.ctx.call("gpe_morton_resort")
+        n = self.n_owned
+        keys = self._view(L.HOME_CELL_IDS, (n,), "<i4").long() & 0xFFFFFFFF
+        perm = self._view(L.PARTICLE_IDS, (n,), "<i4").long() & 0xFFFFFFFF
+        return keys, perm
+
+    def set_active_cells(self, box):
+        self.ctx.call("gpe_set_active_cells", *[int(v) for v in box])
+
+    def refresh(self):
+        self.ctx.call("gpe_refresh")
+
+    def sync(self):
+        self.ctx.sync()
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
+
+    def close(self):
+        self.ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------
+# the sharded state
+# ------------------------------------------------------------------------------------------------------
+class ShardedState:
+    """`State` for one rank of a sharded run.  `engine` holds this rank's owned particles (first n_owned
+    slots) and exposes torch views of its arrays; everything here is device-agnostic torch code."""
+
+    def __init__(self, engine, dec, rank, group=None):
+        self.e, self.dec, self.rank, self.group = engine, dec, rank, group
+        self.ws = dec.world_size
+        self.n_owned = engine.n_owned
+        self.n_ghost = 0
+        self.tables = engine.make_tables(dec, max(1 << 16, engine.capacity() // 4))
+        engine.set_active_cells(dec.active_cells(rank))
+        self.stats = {"migrants": 0, "ghosts": 0, "steps": 0}
+        # gloo moves host tensors only: a GPU engine under a gloo group (tests on a one-GPU box) stages on the host;
+        # with the nccl (= RCCL) backend the device buffers go straight to send/recv
+        self.stage_cpu = (self.ws > 1 and engine.device.type == "cuda" and dist.get_backend(group) == "gloo")
+
+    # -- helpers -------------------------------------------------------------------------------------
+    def _ensure_capacity(self, need):
+        if need > self.e.capacity():
+            self.e.reserve(int(need * 1.25) + 4096)
+            self.e.set_counts(max(self.n_owned, 1), self.n_owned)
+
+    def _gather_counts(self, mine):
+        """mine: int64 [ws, 2] (migrants, ghosts) this rank sends to each peer -> [src, dst, 2] of all."""
+        if self.ws == 1:
+            return mine[None]
+        if self.stage_cpu:
+            mine = mine.cpu()
+        out = [torch.empty_like(mine) for _ in range(self.ws)]
+        dist.all_gather(out, mine, group=self.group)
+        return torch.stack(out)
+
+    def _exchange(self, send_bufs, counts):
+        """send_bufs[peer] = float32 payload or None; counts = [src, dst, 2] host tensor."""
+        recv_bufs, ops = {}, []
+        comm_dev = torch.device("cpu") if self.stage_cpu else self.e.device
+        for peer in range(self.ws):
+            if peer == self.rank:
+                continue
+            nm, ng = int(counts[peer, self.rank, 0]), int(counts[peer, self.rank, 1])
+            if nm + ng:
+                recv_bufs[peer] = torch.empty(nm * 6 + ng * 4, dtype=torch.float32, device=comm_dev)
+                ops.append(dist.P2POp(dist.irecv, recv_bufs[peer], peer, group=self.group))
+            if send_bufs.get(peer) is not None:
+                ops.append(dist.P2POp(dist.isend, send_bufs[peer].to(comm_dev), peer, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if self.stage_cpu:
+            recv_bufs = {p: b.to(self.e.device) for p, b in recv_bufs.items()}
+        return recv_bufs
+
+    # -- one step --------------------------------------------------------------------------------------
+    def exchange(self):
+        """Migrate particles that left this rank's blocks, then (re)build the ghost layer."""
+        e, rank = self.e, self.rank
+        with e.stream_ctx():
+            a = e.arrays()
+            e.set_counts(max(self.n_owned, 1), self.n_owned)               # ghosts of the last step are gone
+            idx, info = e.classify(self.dec, rank, self.tables)
+            owner1 = (info >> 26) & 31                                     # 1 + new owner, 0 = stays here
+            mask = info & 0x03FFFFFF                                       # ranks bordering its current block
+            is_mig = owner1 > 0
+            mig_idx, mig_owner = idx[is_mig], owner1[is_mig].long() - 1
+            mine = torch.zeros((self.ws, 2), dtype=torch.int64, device=e.device)
+            send = {}
+            gid_f = a["gid"].view(torch.float32)
+
+            def ghost_rows(gi):
+                return torch.cat([a["pos"][gi], a["radius"][gi, None], gid_f[gi, None]], 1)
+
+            for peer in range(self.ws):
+                if peer == rank:
+                    continue
+                mi = mig_idx[mig_owner == peer]
+                # ghosts for `peer`: everything in a block bordering it -- a migrant included, unless `peer`
+                # is the migrant's new owner (it then arrives as an owned particle)
+                gi = idx[(((mask >> peer) & 1) != 0) & (owner1 != peer + 1)]
+                if mi.numel() + gi.numel() == 0:
+                    continue
+                mine[peer, 0], mine[peer, 1] = mi.numel(), gi.numel()
+                mrows = torch.cat([a["pos"][mi], a["prev"][mi], a["radius"][mi, None], gid_f[mi, None]], 1).reshape(-1)
+                send[peer] = torch.cat([mrows, ghost_rows(gi).reshape(-1)]).contiguous()
+            # a migrant that still borders this rank stays behind as one of its own ghosts
+            local_ghosts = ghost_rows(idx[is_mig & (((mask >> rank) & 1) != 0)]).clone()
+            counts = self._gather_counts(mine).cpu()
+            recv = self._exchange(send, counts)
+
+            # drop the migrants: fill their holes from the tail (order is free: members sort by order key)
+            k = int(mig_idx.numel())
+            if k:
+                n0 = self.n_owned
+                holes = torch.sort(mig_idx).values
+                tail = torch.arange(n0 - k, n0, device=e.device)
+                tail_keep = tail[~torch.isin(tail, holes)]
+                holes_front = holes[holes < n0 - k]
+                for name in ("pos", "prev", "radius", "gid"):
+                    a[name][holes_front] = a[name][tail_keep]
+                self.n_owned = n0 - k
+            # arrivals: migrants become owned, ghosts follow all owned particles
+            arr_m = [(p, int(counts[p, rank, 0])) for p in sorted(recv)]
+            n_in = sum(c for _, c in arr_m)
+            n_gh = sum(int(counts[p, rank, 1]) for p in recv) + int(local_ghosts.shape[0])
+            self._ensure_capacity(self.n_owned + n_in + n_gh + 1)
+            a = e.arrays()
+            o = self.n_owned
+            for p, c in arr_m:
+                if c:
+                    rows = recv[p][:c * 6].view(c, 6)
+                    a["pos"][o:o + c] = rows[:, 0:2]
+                    a["prev"][o:o + c] = rows[:, 2:4]
+                    a["radius"][o:o + c] = rows[:, 4]
+                    a["gid"][o:o + c] = rows[:, 5].contiguous().view(torch.int32)
+                    o += c
+            self.n_owned = o
+            for p in sorted(recv):
+                cm, cg = int(counts[p, rank, 0]), int(counts[p, rank, 1])
+                if cg:
+                    rows = recv[p][cm * 6:cm * 6 + cg * 4].view(cg, 4)
+                    a["pos"][o:o + cg] = rows[:, 0:2]
+                    a["radius"][o:o + cg] = rows[:, 2]
+                    a["gid"][o:o + cg] = rows[:, 3].contiguous().view(torch.int32)
+                    o += cg
+            cg = int(local_ghosts.shape[0])
+            if cg:
+                a["pos"][o:o + cg] = local_ghosts[:, 0:2]
+                a["radius"][o:o + cg] = local_ghosts[:, 2]
+                a["gid"][o:o + cg] = local_ghosts[:, 3].contiguous().view(torch.int32)
+                o += cg
+            self.n_ghost = o - self.n_owned
+            if self.n_owned == 0:
+                raise RuntimeError("rank %d owns no particle any more (unsupported)" % rank)
+            e.n_owned = self.n_owned
+            e.set_counts(self.n_owned + self.n_ghost, self.n_owned)
+            self.stats["migrants"] += k
+            self.stats["ghosts"] += self.n_ghost
+
+    def resort(self):
+        """The reference's Morton re-sort (particle_sort.rs:58-69) with GLOBAL new indices."""
+        e = self.e
+        with e.stream_ctx():
+            n = self.n_owned
+            e.set_counts(n, n)
+            a = e.arrays()
+            order = torch.argsort(a["gid"][:n].long())                    # ties of the key sort = old index order
+            for name in ("pos", "prev", "radius", "gid"):
+                a[name][:n] = a[name][:n][order]
+            e.n_owned = n
+            keys, _ = e.morton_resort()                                    # arrays now sorted by (key, old index)
+            entries = self.dec.morton_entries()
+            mb = keys >> 6
+            local = torch.bincount(mb, minlength=entries)
+            total = local.clone()
+            if self.ws > 1:
+                if self.stage_cpu:
+                    t = total.cpu()
+                    dist.all_reduce(t, group=self.group)
+                    total = t.to(e.device)
+                else:
+                    dist.all_reduce(total, group=self.group)
+            base = torch.cumsum(total, 0) - total                          # particles of all ranks in earlier blocks
+            first = torch.cumsum(local, 0) - local                         # first local position of each block
+            new_gid = base[mb] + (torch.arange(n, device=e.device) - first[mb])
+            a = e.arrays()
+            a["gid"][:n] = new_gid.to(torch.int32)
+
+    def update(self, dt, resort=False):
+        """state.rs:115-131 for one rank: [re-sort] -> exchange -> collide (owned + ghosts) -> integrate owned."""
+        if resort:
+            # every Morton block's particles must sit on their owner before indices are assigned
+            if self.ws > 1:
+                self.exchange()
+            self.resort()
+        if self.ws > 1:
+            self.exchange()
+        else:
+            self.e.set_counts(self.n_owned, self.n_owned)
+        self.e.step(dt)
+        self.stats["steps"] += 1
+
+    def run(self, dt, steps, resort_every=0, resort_first=True):
+        for s in range(steps):
+            self.update(dt, resort=(s == 0 and resort_first) or (resort_every and s > 0 and s % resort_every == 0))
+
+    def owned(self):
+        """(gid, pos, prev) of the owned particles as host arrays."""
+        self.e.sync()
+        with self.e.stream_ctx():
+            a = self.e.arrays()
+            n = self.n_owned
+            out = (a["gid"][:n].cpu().numpy().astype(np.int64), a["pos"][:n].cpu().numpy(), a["prev"][:n].cpu().numpy())
+        return out

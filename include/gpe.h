@@ -144,7 +144,8 @@ typedef enum gpe_array {
     GPE_COLLISION_CELLS = 7,   /* u32[4n]  CollisionSystem::download_collision_cells (:41)        */
     GPE_NUM_COLLISION_CELLS = 8, /* u32[1] last element of the scanned chunk counts               */
     GPE_CHUNK_OBJ_COUNT = 9,   /* u32[n]   CollisionCellBuilder::chunk_obj_count (scanned)        */
-    GPE_INDIRECT_ARGS = 10     /* u32[3]   collision_cell_builder.wgsl:96-109                     */
+    GPE_INDIRECT_ARGS = 10,    /* u32[3]   collision_cell_builder.wgsl:96-109                     */
+    GPE_ORDER_KEYS = 11        /* u32[n]   sharded runs: global object index of each local particle */
 } gpe_array;
 /* Blocks until the stream is idle, then copies exactly `bytes` (must equal the array's size). */
 gpe_status gpe_download(gpe_ctx *ctx, gpe_array what, void *dst, uint64_t bytes);
@@ -172,6 +173,36 @@ gpe_status gpe_sort_scatter_pass_u32(gpe_ctx *ctx, const uint32_t *d_keys_a, con
                                      uint32_t *d_keys_b, uint32_t *d_payload_b, uint64_t n, uint32_t shift);
 /* PrefixSum::execute (prefix_sum.rs:143-160): in-place inclusive u32 scan, wrap-around add. */
 gpe_status gpe_inclusive_scan_u32(gpe_ctx *ctx, uint32_t *d_data, uint64_t n);
+
+/* ---- sharding support (the reference is single-device, so no counterpart there) ---- */
+/* One context per GPU holds the particles whose home cell that rank owns, followed by ghost copies of
+ * the neighbours' particles within 5 cells of its region (the dependency cone of the four colour passes).
+ * Ghosts take part in collisions but are not integrated; their results are discarded.  The host side
+ * (gpu-physics-engine_amd/sharded.py) moves migrants and ghosts between ranks over RCCL point-to-point. */
+/* Grow every buffer to hold `capacity` particles, keeping the current ones. */
+gpe_status gpe_reserve(gpe_ctx *ctx, uint64_t capacity);
+gpe_status gpe_capacity(const gpe_ctx *ctx, uint64_t *capacity);
+/* The first n_owned of the n_total resident particles are this rank's own (integrated by K12); the rest
+ * are ghosts written by the caller through gpe_device_ptr(GPE_POS / GPE_RADIUS / GPE_ORDER_KEYS). */
+gpe_status gpe_set_counts(gpe_ctx *ctx, uint64_t n_total, uint64_t n_owned);
+/* Order the members of a cell by GPE_ORDER_KEYS[local index] (the particle's index in the unsharded
+ * system) instead of by local index, so a sharded run reproduces the single-device pair order. */
+gpe_status gpe_use_order_keys(gpe_ctx *ctx, int32_t enable);
+/* Cells [cx0..cx1] x [cy0..cy1] contain every resident particle: the native tile grid is cut to it. */
+gpe_status gpe_set_active_cells(gpe_ctx *ctx, int32_t cx0, int32_t cy0, int32_t cx1, int32_t cy1);
+/* The context's hipStream_t, so that a host framework can enqueue its own packing / exchange work in
+ * order with the library's kernels (torch.cuda.ExternalStream). */
+gpe_status gpe_stream_handle(gpe_ctx *ctx, void **hip_stream);
+/* Re-derive the native pipeline's configuration after the caller changed particles in place. */
+gpe_status gpe_refresh(gpe_ctx *ctx);
+/* For every owned particle whose 8x8-cell block (row-major blocks_x x blocks_y over the world) is owned by
+ * another rank (a migrant) and/or borders other ranks (a ghost for them), append (local index, info):
+ * info bits 0-25 = the block's destination-rank mask, bits 26-30 = 1 + the block's owner when that is not
+ * my_rank (at most 26 ranks).  *d_out_count (device, zeroed by the caller) receives the number appended
+ * (entries beyond out_capacity are dropped). */
+gpe_status gpe_shard_classify(gpe_ctx *ctx, const uint8_t *d_owner_of_block, const uint32_t *d_dest_mask_of_block,
+                              int32_t blocks_x, int32_t blocks_y, uint32_t my_rank, uint32_t *d_out_index,
+                              uint32_t *d_out_info, uint32_t *d_out_count, uint64_t out_capacity);
 
 /* ---- profiling (wgpu_profiler scopes threaded through every reference call) ------------------ */
 typedef struct gpe_timing {

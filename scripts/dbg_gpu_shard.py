@@ -1,0 +1,39 @@
+import importlib, os, sys, socket
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def worker(rank, ws, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    gpe = importlib.import_module("gpu-physics-engine_amd")
+    sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+    n, world, gravity = 40000, (420.0, 300.0), (40.0, 0.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=5)
+    dec = sharded.Decomposition(world, np.float32(1.1), ws)
+    mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+    eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, gravity=gravity, device=0)
+    st = sharded.ShardedState(eng, dec, rank)
+    ref = None
+    if rank == 0:
+        ref = gpe.State(pos, rad, world=world, gravity=gravity, mode=gpe.MODE_NATIVE)
+    for s in range(10):
+        resort = s in (0, 6)
+        st.update(0.05, resort=resort)
+        gid, p, q = st.owned()
+        allg = [None] * ws
+        dist.all_gather_object(allg, (gid, p, st.n_owned, st.n_ghost, st.stats["migrants"]))
+        if rank == 0:
+            ref.update(0.05, resort=resort)
+            g = np.concatenate([x[0] for x in allg]); pp = np.concatenate([x[1] for x in allg])
+            u, c = np.unique(g, return_counts=True)
+            want = ref.positions()
+            ok = len(u) == n and np.array_equal(pp[np.argsort(g)], want)
+            nbad = -1
+            if len(u) == n: nbad = int((pp[np.argsort(g)] != want).any(axis=1).sum())
+            print("step", s, "owned", [x[2] for x in allg], "ghost", [x[3] for x in allg], "mig", [x[4] for x in allg], "unique", len(u), "dups", int((c > 1).sum()), "max", g.max(), "exact", ok, "nbad", nbad, flush=True)
+    dist.destroy_process_group()
+if __name__ == "__main__":
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(worker, args=(2, port), nprocs=2, join=True)

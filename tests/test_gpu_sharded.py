@@ -1,0 +1,76 @@
+"""GPU (-m gpu): two ranks sharing cuda:0 (gloo, staged through the host) run the sharded step on libgpe.so
+(native kernels, order keys, ghost band, migration, global re-sort indices); the union of their particles must
+be bit-identical to the single-context run.  The nccl/RCCL transport differs from this test only in where the
+send/recv buffers live (gpu-physics-engine_amd/sharded.py: stage_cpu)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, ws, port, n, world, gravity, steps, resort_at, dt, seed, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
+        cs = np.float32(0.5) * np.float32(2.2)
+        dec = sharded.Decomposition(world, cs, ws)
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, gravity=gravity, device=0)
+        st = sharded.ShardedState(eng, dec, rank)
+        for s in range(steps):
+            st.update(dt, resort=(s in resort_at))
+        gid, p, q = st.owned()
+        eng.ctx.sync()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=gid, pos=p, prev=q,
+                 migrants=st.stats["migrants"], ghosts=st.stats["ghosts"])
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ws,n,world,gravity", [
+    (2, 40_000, (420.0, 300.0), (40.0, 0.0)),
+    (4, 60_000, (500.0, 380.0), (25.0, -30.0)),
+])
+def test_two_ranks_one_gpu_equal_single_context(gpe, tmp_path, ws, n, world, gravity):
+    steps, dt, seed, resort_at = 14, 0.05, 5, (0, 6)
+    port = _free_port()
+    mp.spawn(_worker, args=(ws, port, n, world, gravity, steps, resort_at, dt, seed, str(tmp_path)), nprocs=ws, join=True)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
+    ref = gpe.State(pos, rad, world=world, gravity=gravity, mode=gpe.MODE_NATIVE)
+    for s in range(steps):
+        ref.update(dt, resort=(s in resort_at))
+    want_pos, want_prev = ref.positions(), ref.previous_positions()
+    ref.close()
+    gids, poss, prevs, migrants, ghosts = [], [], [], 0, 0
+    for r in range(ws):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        gids.append(d["gid"]); poss.append(d["pos"]); prevs.append(d["prev"])
+        migrants += int(d["migrants"]); ghosts += int(d["ghosts"])
+    gid = np.concatenate(gids)
+    assert np.array_equal(np.sort(gid), np.arange(n))
+    order = np.argsort(gid)
+    assert migrants > 0 and ghosts > 0
+    assert np.array_equal(np.concatenate(poss)[order], want_pos)
+    assert np.array_equal(np.concatenate(prevs)[order], want_prev)

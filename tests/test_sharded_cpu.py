@@ -1,0 +1,109 @@
+"""CPU (gloo, world_size 2 and 4): the sharding logic of gpu-physics-engine_amd/sharded.py -- block ownership, one-block
+ghost band, migration, globally consistent re-sort indices -- with an oracle-backed engine per rank
+(tests/_cpu_engine.py).  The sharded run must be BIT-IDENTICAL to the single-process oracle run."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _scene(n, world, seed):
+    rng = np.random.default_rng(seed)
+    pos = (rng.random((n, 2), dtype=np.float32) * np.array(world, np.float32)).astype(np.float32)
+    rad = np.full(n, 0.5, np.float32)
+    return pos, rad
+
+
+def _worker(rank, ws, port, n, world, gravity, steps, resort_at, dt, seed, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        from oracle import oracle as orc
+        from _cpu_engine import OracleEngine
+        pos, rad = _scene(n, world, seed)
+        cs = np.float32(0.5) * np.float32(2.2)
+        dec = sharded.Decomposition(world, cs, ws)
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        eng = OracleEngine(orc, pos[mine], rad[mine], mine, world, cs, gravity=gravity)
+        st = sharded.ShardedState(eng, dec, rank)
+        for s in range(steps):
+            st.update(dt, resort=(s in resort_at))
+        gid, p, q = st.owned()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=gid, pos=p, prev=q,
+                 migrants=st.stats["migrants"], ghosts=st.stats["ghosts"])
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference(n, world, gravity, steps, resort_at, dt, seed):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    pos, rad = _scene(n, world, seed)
+    sim = orc.Sim(pos, rad, orc.default_params(world[0], world[1], 0.5, gravity=gravity))
+    for s in range(steps):
+        sim.step(dt, resort=(s in resort_at))
+    return sim.pos, sim.prev
+
+
+@pytest.mark.parametrize("ws,world,gravity", [
+    (2, (150.0, 100.0), (40.0, 0.0)),        # two ranks side by side, drift across the cut
+    (4, (160.0, 140.0), (25.0, -30.0)),      # 2 x 2 ranks, drift through the corner
+])
+def test_sharded_equals_single_process(tmp_path, ws, world, gravity):
+    n, steps, dt, seed = 5000, 14, 0.05, 11
+    resort_at = (0, 6)
+    port = _free_port()
+    mp.spawn(_worker, args=(ws, port, n, world, gravity, steps, resort_at, dt, seed, str(tmp_path)), nprocs=ws, join=True)
+    want_pos, want_prev = _reference(n, world, gravity, steps, resort_at, dt, seed)
+    gids, poss, prevs, migrants, ghosts = [], [], [], 0, 0
+    for r in range(ws):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        gids.append(d["gid"]); poss.append(d["pos"]); prevs.append(d["prev"])
+        migrants += int(d["migrants"]); ghosts += int(d["ghosts"])
+    gid = np.concatenate(gids)
+    assert np.array_equal(np.sort(gid), np.arange(n)), "every particle owned by exactly one rank"
+    order = np.argsort(gid)
+    got_pos, got_prev = np.concatenate(poss)[order], np.concatenate(prevs)[order]
+    assert migrants > 0 and ghosts > 0, "the scene must exercise migration and the ghost band"
+    assert np.array_equal(got_pos, want_pos)
+    assert np.array_equal(got_prev, want_prev)
+
+
+def test_decomposition_tables():
+    sys.path.insert(0, ROOT)
+    sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+    dec = sharded.Decomposition((3048.0, 1048.0), np.float32(1.1), 8)
+    assert dec.px * dec.py == 8
+    assert dec.owner.shape == (dec.by, dec.bx)
+    assert set(np.unique(dec.owner)) == set(range(8))
+    # a block's destination mask never names its own owner and is non-zero exactly along the cuts
+    own_bit = np.uint32(1) << dec.owner.astype(np.uint32)
+    assert not (dec.dest_mask & own_bit).any()
+    interior = dec.dest_mask == 0
+    assert interior.sum() > 0.8 * interior.size
+    for r in range(8):
+        x0, y0, x1, y1 = dec.rect_blocks(r)
+        assert (dec.owner[y0:y1, x0:x1] == r).all()
+        cx0, cy0, cx1, cy1 = dec.active_cells(r)
+        assert cx0 <= x0 * 8 and cx1 >= min(dec.gx, x1 * 8) - 1
