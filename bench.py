@@ -104,7 +104,7 @@ def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gra
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timings = st.ctx.timings()
@@ -112,6 +112,57 @@ def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gra
     assert np.isfinite(p).all(), "non-finite positions after the run"
     st.close()
     return elapsed, timings, world
+
+
+def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gravity, device):
+    """N > 1: one shard per GPU (gpu-physics-engine_amd/sharded.py): block ownership, one-block ghost band and
+    migration over RCCL point-to-point every step.  Weak scaling: every rank fills its own rectangle of the
+    world with n_per_gpu particles at the reference density."""
+    import numpy as np
+    sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+    px, py = sharded._factor(world_size)
+    w1 = gpe.scenes.world_for(n_per_gpu)
+    world = (w1[0] * px, w1[1] * py)
+    cs = np.float32(gpe.scenes.REF_RADIUS) * np.float32(2.2)
+    dec = sharded.Decomposition(world, cs, world_size, grid=(px, py))
+    x0, y0, x1, y1 = dec.rect_units(rank)
+    rng = np.random.default_rng(0x5EED + rank)
+    pos = np.empty((n_per_gpu, 2), np.float32)
+    pos[:, 0] = x0 + rng.random(n_per_gpu, dtype=np.float32) * np.float32((x1 - x0) * 0.999999)
+    pos[:, 1] = y0 + rng.random(n_per_gpu, dtype=np.float32) * np.float32((y1 - y0) * 0.999999)
+    keep = dec.owner_of(pos) == rank                      # float rounding at the cut: keep what this rank owns
+    pos = np.ascontiguousarray(pos[keep])
+    rad = np.full(len(pos), gpe.scenes.REF_RADIUS, np.float32)
+    gid = np.arange(len(pos), dtype=np.int64) + rank * n_per_gpu
+    log("[rank %d] shard: %d particles in [%.1f,%.1f)x[%.1f,%.1f) of %.1f x %.1f" % (rank, len(pos), x0, x1, y0, y1, world[0], world[1]))
+    g = (0.0, -9.81) if gravity == "on" else (0.0, 0.0)
+    eng = sharded.GpeEngine(pos, rad, gid, world, gravity=g, device=device)
+    del pos, rad, gid
+    st = sharded.ShardedState(eng, dec, rank)
+    dt = 1.0 / 60.0
+    st.run(dt, warmup, resort_every=RESORT_EVERY, resort_first=True)
+    eng.sync()
+    eng.ctx.set_profiling(True)
+    eng.ctx.reset_timings()
+    st.stats = {"migrants": 0, "ghosts": 0, "steps": 0}
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st.run(dt, steps, resort_every=RESORT_EVERY, resort_first=False)
+    eng.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    timings = eng.ctx.timings()
+    info = {"owned": st.n_owned, "ghosts_per_step": st.stats["ghosts"] / max(1, st.stats["steps"]),
+            "migrants_per_step": st.stats["migrants"] / max(1, st.stats["steps"]), "process_grid": [px, py]}
+    _, p, _ = st.owned()
+    assert np.isfinite(p).all(), "non-finite positions after the run"
+    eng.close()
+    return elapsed, timings, world, info
 
 
 def cpu_baseline(gpe, n, budget_s=15.0):
@@ -145,28 +196,51 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # GPE_BENCH_BACKEND=gloo GPE_BENCH_SHARE_GPU=1: rehearse the N > 1 path on a one-GPU box (all ranks on cuda:0,
+    # exchange staged through the host); the real run is one rank per GPU over nccl (= RCCL).
+    backend = os.environ.get("GPE_BENCH_BACKEND", "nccl")
+    if os.environ.get("GPE_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
     gpe = importlib.import_module("gpu-physics-engine_amd")
     gpe._lib.load()
 
     n = args.particles
-    elapsed, timings, world = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
-                                           args.mode, args.gravity, local_rank)
+    shard_info = None
+    if world_size > 1:
+        elapsed, timings, world, shard_info = run_sharded(gpe, torch, dist, rank, world_size, n, args.steps,
+                                                          args.warmup, args.gravity, local_rank)
+    else:
+        elapsed, timings, world = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
+                                               args.mode, args.gravity, local_rank)
+    extra_run = None
+    if not args.no_extra and args.extra_particles != n:
+        ne = args.extra_particles
+        log("extra workload: %d particles per GPU, gravity on ..." % ne)
+        if world_size > 1:
+            extra_run = run_sharded(gpe, torch, dist, rank, world_size, ne, args.extra_steps, 5, "on", local_rank)
+        else:
+            extra_run = run_workload(gpe, torch, None, 0, 1, ne, args.extra_steps, 5, args.mode, "on", local_rank) + (None,)
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
+    ngpu = max(1, world_size)
     ms_per_step = elapsed / args.steps * 1e3
     steps_per_s = args.steps / elapsed
-    roofs = kernel_rooflines(timings, n, args.mode)
+    mode = "native" if world_size > 1 else args.mode
+    roofs = kernel_rooflines(timings, n, mode)
     for name, (tot, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0]):
         extra = ""
         if name in roofs:
@@ -177,7 +251,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if dom and os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.mode, {}).get(dom[0], {}).get(str(n))
+            traffic = json.load(open(tpath)).get(mode, {}).get(dom[0], {}).get(str(n))
         except Exception:
             traffic = None
     roofline = None
@@ -187,42 +261,50 @@ def main():
                     "bytes_per_launch": dom[1]["bytes"], "avg_launch_ms": round(dom[1]["avg_ms"], 5),
                     "launches": dom[1]["calls"]}
 
+    # Whole-job value: every GPU advances one shard of `particles_per_gpu` particles per step, so the job
+    # completes n_gpus shard-steps per step (== plain steps/s at n_gpus = 1).
     result = {
-        "metric": "physics_steps_per_sec", "value": round(steps_per_s * 1.0, 3), "unit": "steps/s",
+        "metric": "physics_steps_per_sec", "value": round(steps_per_s * ngpu, 3), "unit": "steps/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u32",
         "data": "synthetic",
         "config": {"workload": "%d particles per GPU, gravity %s, world %.1f x %.1f, radius 0.5, uniform random "
-                               "(BASELINE.json configs[1] at 1M)" % (n, args.gravity, world[0], world[1]),
-                   "particles_per_gpu": n, "mode": args.mode, "resort_every": RESORT_EVERY, "dt": 1.0 / 60.0,
-                   "particle_steps_per_sec": round(steps_per_s * n * args.gpus, 1),
-                   "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * n * args.gpus * steps_per_s / 1e9, 2),
+                               "(BASELINE.json configs[1] at 1M per GPU)" % (n, args.gravity, world[0], world[1]),
+                   "particles_per_gpu": n, "particles_total": n * ngpu, "mode": mode, "resort_every": RESORT_EVERY,
+                   "dt": 1.0 / 60.0,
+                   "value_is": "steps/s of the whole system x n_gpus shards (one shard = particles_per_gpu particles)",
+                   "system_steps_per_sec": round(steps_per_s, 3),
+                   "particle_steps_per_sec": round(steps_per_s * n * ngpu, 1),
+                   "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * n * ngpu * steps_per_s / 1e9, 2),
                    "step_frac_of_hbm_roofline": round(ALGO_BYTES_PER_PARTICLE * n * steps_per_s / 1e9 / HBM_PEAK_GBS, 5),
-                   "reference_frame_ms_rx6800xt_incl_render": 3.66 if n == 1_000_000 else None},
+                   "reference_frame_ms_rx6800xt_incl_render": 3.66 if n == 1_000_000 else None,
+                   "sharding": shard_info},
         "roofline": roofline,
     }
     if args.gpus == 1 and not args.no_cpu_baseline:
         log("cpu baseline (oracle, 1 thread) ...")
         result["cpu_baseline"] = cpu_baseline(gpe, min(n, 1_000_000))
         result["cpu_baseline"]["value"] = round(result["cpu_baseline"]["value"], 4)
-    if args.gpus == 1 and not args.no_extra and args.extra_particles != n:
+    if extra_run is not None:
+        el2, tim2, world2, info2 = extra_run
         ne = args.extra_particles
-        log("extra workload: %d particles, gravity on ..." % ne)
-        el2, tim2, world2 = run_workload(gpe, torch, None, 0, 1, ne, args.extra_steps, 5, args.mode, "on", local_rank)
         sps2 = args.extra_steps / el2
-        roofs2 = kernel_rooflines(tim2, ne, args.mode)
+        roofs2 = kernel_rooflines(tim2, ne, mode)
         for name, (tot, calls) in sorted(tim2.items(), key=lambda kv: -kv[1][0]):
             extra = "  %.0f GB/s algorithmic" % roofs2[name]["GBps"] if name in roofs2 else ""
             log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
         dom2 = max(roofs2.items(), key=lambda kv: kv[1]["total_ms"]) if roofs2 else None
         result["extra_workloads"] = [{
-            "workload": "%d particles, gravity on (0,-9.81), world %.1f x %.1f (BASELINE.json configs[2])" % (ne, world2[0], world2[1]),
-            "steps": args.extra_steps, "steps_per_sec": round(sps2, 3), "ms_per_step": round(1e3 / sps2, 4),
-            "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * ne * sps2 / 1e9, 1),
-            "step_frac_of_hbm_roofline": round(ALGO_BYTES_PER_PARTICLE * ne * sps2 / 1e9 / HBM_PEAK_GBS, 4),
+            "workload": "%d particles per GPU (%d in all), gravity on (0,-9.81), world %.1f x %.1f (BASELINE.json "
+                        "configs[2] / [4])" % (ne, ne * ngpu, world2[0], world2[1]),
+            "n_gpus": ngpu, "steps": args.extra_steps, "system_steps_per_sec": round(sps2, 3),
+            "shard_steps_per_sec": round(sps2 * ngpu, 3), "ms_per_step": round(1e3 / sps2, 4),
+            "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * ne * ngpu * sps2 / 1e9, 1),
+            "step_frac_of_hbm_roofline_per_gpu": round(ALGO_BYTES_PER_PARTICLE * ne * sps2 / 1e9 / HBM_PEAK_GBS, 4),
             "dominant_kernel": dom2[0] if dom2 else None,
             "dominant_kernel_GBps": round(dom2[1]["GBps"], 1) if dom2 else None,
             "dominant_kernel_frac": round(dom2[1]["GBps"] / HBM_PEAK_GBS, 4) if dom2 else None,
+            "sharding": info2,
         }]
     print(json.dumps(result), flush=True)
     if dist is not None:
