@@ -16,7 +16,22 @@
 // for tiles that are already resident => forward progress whatever the dispatch order.  Status
 // words carry an epoch (sort call x pass), so the array is never cleared between passes; spins are
 // bounded and report through an error word instead of hanging the GPU.
+#include <stdio.h>
+
 #include "gpe_internal.h"
+
+#ifdef GPE_OS_STAMPS
+#define OS_STAMP(i)                                                                   \
+    do {                                                                              \
+        if (threadIdx.x == 0 && (s_tile & 63u) == 7u) {                               \
+            const long long _t = clock64();                                           \
+            atomicAdd(&ctl[16 + (i)], (uint32_t)(_t - _t_prev));                      \
+            _t_prev = _t;                                                             \
+        }                                                                             \
+    } while (0)
+#else
+#define OS_STAMP(i) do {} while (0)
+#endif
 
 namespace gpe {
 
@@ -110,6 +125,9 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_tile;
 
+#ifdef GPE_OS_STAMPS
+    long long _t_prev = clock64();
+#endif
     if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[pass], 1u);     // ticket: tiles start in ticket order
 #pragma unroll
     for (int i = 0; i < kOsWaves; ++i) s_whist[i][threadIdx.x] = 0;
@@ -132,6 +150,10 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
         if (IOTA) val[k] = (uint32_t)idx;
         else val[k] = valid ? vals_in[idx] : 0u;
     }
+#ifdef GPE_OS_STAMPS
+    { uint32_t acc = 0; for (int k = 0; k < kOsItems; ++k) acc += key[k] + val[k]; asm volatile("" :: "v"(acc)); }
+    OS_STAMP(0);
+#endif
     volatile uint32_t *wh = s_whist[w];
 #pragma unroll
     for (int k = 0; k < kOsItems; ++k) {
@@ -147,53 +169,80 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
         rank[k] = (uint16_t)(pre + below);
     }
     __syncthreads();
+    OS_STAMP(1);
 
-    // one thread per digit: tile count, wave offsets, publish, look back, publish prefix
+    // one thread per digit: tile count, wave offsets, publish the tile's aggregate
+    const uint32_t d = threadIdx.x;
+    u64 *mine = status + (uint64_t)tile * 256 + d;
+    uint32_t count;
     {
-        const uint32_t d = threadIdx.x;
         const uint32_t c0 = s_whist[0][d], c1 = s_whist[1][d], c2 = s_whist[2][d], c3 = s_whist[3][d];
         s_whist[0][d] = 0; s_whist[1][d] = c0; s_whist[2][d] = c0 + c1; s_whist[3][d] = c0 + c1 + c2;
-        const uint32_t count = c0 + c1 + c2 + c3;
-        u64 *mine = status + (uint64_t)tile * 256 + d;
+        count = c0 + c1 + c2 + c3;
         if (tile > 0)
             __hip_atomic_store(mine, status_pack(epoch, kFlagAggregate, count), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t before = 0;                                   // digit d in tiles [0, tile)
-        bool failed = false;
-        for (int64_t t = (int64_t)tile - 1; t >= 0;) {
-            const u64 *p = status + (uint64_t)t * 256 + d;
-            u64 s = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t spins = 0;
-            while ((uint32_t)(s >> 34) != epoch || ((s >> 32) & 3ull) == 0ull) {
-                if (++spins > kSpinLimit) { failed = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-                s = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (failed) break;
-            before += (uint32_t)s;
-            if (((s >> 32) & 3ull) == kFlagPrefix) break;
-            --t;
-        }
-        if (failed) atomicOr(&ctl[4], 1u);
-        __hip_atomic_store(mine, status_pack(epoch, kFlagPrefix, before + count), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t excl = block256_exclusive_scan(count, s_w, nullptr);
-        s_excl[d] = excl;
-        s_delta[d] = bases4[pass * 256 + d] + before - excl;
+        s_excl[d] = block256_exclusive_scan(count, s_w, nullptr);
     }
     __syncthreads();
 
+    // reorder the tile in LDS by digit (stable) BEFORE looking back: it needs only tile-local offsets, and
+    // meanwhile the predecessors get on with publishing their inclusive prefixes (shorter walk, no spinning)
 #pragma unroll
     for (int k = 0; k < kOsItems; ++k) {
         const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
         if (idx < n) {
-            const uint32_t d = (key[k] >> shift) & 255u;
-            const uint32_t slot = s_excl[d] + s_whist[w][d] + rank[k];
+            const uint32_t dk = (key[k] >> shift) & 255u;
+            const uint32_t slot = s_excl[dk] + s_whist[w][dk] + rank[k];
             s_keys[slot] = key[k];
             s_vals[slot] = val[k];
         }
     }
+    OS_STAMP(2);
+
+    // decoupled look-back, a WINDOW of predecessors per memory round trip
+    {
+        uint32_t before = 0;                                   // digit d in tiles [0, tile)
+        bool failed = false;
+        uint32_t hops = 0, total_spins = 0;
+        constexpr int kWin = 8;
+        bool done = (tile == 0);
+        for (int64_t t = (int64_t)tile - 1; !done && !failed; t -= kWin) {
+            u64 sw[kWin];
+#pragma unroll
+            for (int i = 0; i < kWin; ++i)
+                sw[i] = (t - i >= 0) ? __hip_atomic_load(status + (uint64_t)(t - i) * 256 + d, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT)
+                                     : status_pack(epoch, kFlagPrefix, 0u);       // before tile 0: nothing
+#pragma unroll
+            for (int i = 0; i < kWin; ++i) {
+                if (done || failed) break;
+                u64 sv = sw[i];
+                uint32_t spins = 0;
+                while ((uint32_t)(sv >> 34) != epoch || ((sv >> 32) & 3ull) == 0ull) {   // not published yet
+                    if (++spins > kSpinLimit) { failed = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    sv = __hip_atomic_load(status + (uint64_t)(t - i) * 256 + d, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (failed) break;
+                ++hops; total_spins += spins;
+                before += (uint32_t)sv;
+                if (((sv >> 32) & 3ull) == kFlagPrefix) done = true;
+            }
+        }
+#ifdef GPE_OS_STAMPS
+        if ((s_tile & 63u) == 7u && d == 0) { atomicAdd(&ctl[24], hops); atomicAdd(&ctl[25], total_spins); atomicAdd(&ctl[26], 1u); }
+#else
+        (void)hops; (void)total_spins;
+#endif
+        if (failed) atomicOr(&ctl[4], 1u);
+        __hip_atomic_store(mine, status_pack(epoch, kFlagPrefix, before + count), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        s_delta[d] = bases4[pass * 256 + d] + before - s_excl[d];
+    }
     __syncthreads();
+    OS_STAMP(1 + 0 * 2);
     for (uint32_t j = threadIdx.x; j < tile_n; j += kOsBlock) {
         const uint32_t kk = s_keys[j];
         const uint32_t d = (kk >> shift) & 255u;
@@ -201,6 +250,7 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
         keys_out[dst] = kk;
         vals_out[dst] = s_vals[j];
     }
+    OS_STAMP(3);
 }
 
 static uint64_t os_tiles(uint64_t n) { return (n + kOsTile - 1) / kOsTile; }
@@ -288,6 +338,21 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
     }
     if (out_keys) *out_keys = ka;
     if (out_vals) *out_vals = va;
+#ifdef GPE_OS_STAMPS
+    {
+        static int calls = 0;
+        if (++calls % 10 == 0) {
+            uint32_t h[64];
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipMemcpy(h, ws.ctl, sizeof(h), hipMemcpyDeviceToHost);
+            const double nt = h[26] ? (double)h[26] : 1.0;
+            fprintf(stderr, "[os stamps] n=%llu passes=%d sampled=%u  load %.0f  rank %.0f  lookback %.0f  reorder+write %.0f cyc;"
+                            " hops/tile %.1f spins/tile %.1f\n", (unsigned long long)n, passes, h[26], h[16] / nt, h[17] / nt,
+                    h[18] / nt, h[19] / nt, h[24] / nt, h[25] / nt);
+        }
+        (void)hipMemsetAsync(ws.ctl + 16, 0, 16 * sizeof(uint32_t), c->stream);
+    }
+#endif
     return GPE_OK;
 }
 
