@@ -689,7 +689,10 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     GPE_TRY(onesweep_zero_hist(c));
     {
         Scope s(c, "native/hash");
-        hipLaunchKernelGGL(k_native_hash, dim3(stream_grid(n)), dim3(kStreamBlock), 0, c->stream, c->pos, n,
+        // every workgroup flushes up to 1024 histogram bins with global atomics: at least 16 keys per lane
+        // per workgroup keeps that flush small next to the streaming work
+        const int grid = std::min(stream_grid(n), std::max(1, (int)(n / (16 * kStreamBlock))));
+        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kStreamBlock), 0, c->stream, c->pos, n,
                            c->cell_size, N.gx, N.gy, N.keys, c->os_ws.hist4, N.tile_ctl);
         GPE_HIP(c, hipGetLastError());
     }

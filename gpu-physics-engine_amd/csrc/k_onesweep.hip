@@ -35,10 +35,16 @@
 
 namespace gpe {
 
-constexpr int kOsBlock = 256;
+#ifndef GPE_OS_WIN
+#define GPE_OS_WIN 8
+#endif
+#ifndef GPE_OS_MINWAVES
+#define GPE_OS_MINWAVES 4
+#endif
+constexpr int kOsBlock = 512;
 constexpr int kOsWaves = kOsBlock / 64;
 constexpr int kOsItems = 16;
-constexpr int kOsTile = kOsBlock * kOsItems;     // 4096 keys
+constexpr int kOsTile = kOsBlock * kOsItems;     // 8192 keys
 constexpr int kOsWaveSpan = 64 * kOsItems;
 
 constexpr uint64_t kFlagAggregate = 1ull;        // value = this tile's count of the digit
@@ -63,7 +69,7 @@ __device__ __forceinline__ uint64_t os_match_digit(uint32_t d, bool valid)
 }
 
 // 1. all four digit histograms in one read of the keys: hist4[p*256 + d]
-__global__ __launch_bounds__(kOsBlock) void k_os_hist4(const uint32_t *__restrict__ keys, uint64_t n,
+__global__ __launch_bounds__(kStreamBlock) void k_os_hist4(const uint32_t *__restrict__ keys, uint64_t n,
                                                         uint32_t *__restrict__ hist4)
 {
     __shared__ uint32_t s_hist[4 * 256];
@@ -106,10 +112,29 @@ __device__ __forceinline__ u64 status_pack(uint32_t epoch, uint64_t flag, uint32
     return ((u64)epoch << 34) | (flag << 32) | (u64)value;
 }
 
+// exclusive scan of one value per thread over the kOsBlock threads of the pass kernel
+__device__ __forceinline__ uint32_t os_block_exclusive_scan(uint32_t v, uint32_t *s_w)
+{
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < kOsWaves; ++i)
+        if (i < w) base += s_w[i];
+    __syncthreads();
+    return base + inc - v;
+}
+
 // 3. one digit pass.  IOTA: the payload of input element i is i itself (first pass of a sort whose
 //    payload is the identity), saving the payload read.
+//    512 threads x 16 keys = 8192 keys per tile: the look-back reads 2 KB of status per predecessor and
+//    tile, so larger tiles halve that traffic per key; keys and payloads are reordered through ONE
+//    32 KB LDS buffer, one after the other (42 KB of LDS per workgroup).
 template <bool IOTA>
-__global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict__ keys_in,
+__global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uint32_t *__restrict__ keys_in,
                                                        const uint32_t *__restrict__ vals_in,
                                                        uint32_t *__restrict__ keys_out,
                                                        uint32_t *__restrict__ vals_out, uint64_t n,
@@ -117,20 +142,18 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
                                                        const uint32_t *__restrict__ bases4, u64 *status,
                                                        uint32_t *ctl, uint32_t epoch)
 {
-    __shared__ uint32_t s_keys[kOsTile];
-    __shared__ uint32_t s_vals[kOsTile];
+    __shared__ uint32_t s_stage[kOsTile];
     __shared__ uint32_t s_whist[kOsWaves][256];
     __shared__ uint32_t s_excl[256];
     __shared__ uint32_t s_delta[256];
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[kOsWaves];
     __shared__ uint32_t s_tile;
 
 #ifdef GPE_OS_STAMPS
     long long _t_prev = clock64();
 #endif
     if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[pass], 1u);     // ticket: tiles start in ticket order
-#pragma unroll
-    for (int i = 0; i < kOsWaves; ++i) s_whist[i][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kOsWaves * 256; i += kOsBlock) (&s_whist[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
 
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
     const uint32_t tile_n = (uint32_t)((n - tile_base < (uint64_t)kOsTile) ? (n - tile_base) : kOsTile);
 
     uint32_t key[kOsItems], val[kOsItems];
-    uint16_t rank[kOsItems];
+    uint16_t slot[kOsItems];                                       // rank in the wave, then slot in the tile
 #pragma unroll
     for (int k = 0; k < kOsItems; ++k) {
         const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
@@ -154,6 +177,8 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
     { uint32_t acc = 0; for (int k = 0; k < kOsItems; ++k) acc += key[k] + val[k]; asm volatile("" :: "v"(acc)); }
     OS_STAMP(0);
 #endif
+    // Rank: (round k, lane) is the input order inside the wave's span, so
+    // rank = keys of this digit in earlier rounds + lower lanes of this round  => stable.
     volatile uint32_t *wh = s_whist[w];
 #pragma unroll
     for (int k = 0; k < kOsItems; ++k) {
@@ -166,46 +191,50 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
         __builtin_amdgcn_wave_barrier();
         if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();
-        rank[k] = (uint16_t)(pre + below);
+        slot[k] = (uint16_t)(pre + below);
     }
     __syncthreads();
     OS_STAMP(1);
 
     // one thread per digit: tile count, wave offsets, publish the tile's aggregate
-    const uint32_t d = threadIdx.x;
+    const uint32_t d = threadIdx.x & 255u;
+    const bool digit_thread = threadIdx.x < 256;
     u64 *mine = status + (uint64_t)tile * 256 + d;
-    uint32_t count;
-    {
-        const uint32_t c0 = s_whist[0][d], c1 = s_whist[1][d], c2 = s_whist[2][d], c3 = s_whist[3][d];
-        s_whist[0][d] = 0; s_whist[1][d] = c0; s_whist[2][d] = c0 + c1; s_whist[3][d] = c0 + c1 + c2;
-        count = c0 + c1 + c2 + c3;
+    uint32_t count = 0;
+    if (digit_thread) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < kOsWaves; ++i) { const uint32_t ci = s_whist[i][d]; s_whist[i][d] = run; run += ci; }
+        count = run;
         if (tile > 0)
             __hip_atomic_store(mine, status_pack(epoch, kFlagAggregate, count), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        s_excl[d] = block256_exclusive_scan(count, s_w, nullptr);
+    }
+    {
+        const uint32_t ex = os_block_exclusive_scan(count, s_w);   // threads >= 256 contribute 0, come last
+        if (digit_thread) s_excl[d] = ex;
     }
     __syncthreads();
 
-    // reorder the tile in LDS by digit (stable) BEFORE looking back: it needs only tile-local offsets, and
+    // reorder the keys in LDS by digit (stable) BEFORE looking back: it needs only tile-local offsets, and
     // meanwhile the predecessors get on with publishing their inclusive prefixes (shorter walk, no spinning)
 #pragma unroll
     for (int k = 0; k < kOsItems; ++k) {
         const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
         if (idx < n) {
             const uint32_t dk = (key[k] >> shift) & 255u;
-            const uint32_t slot = s_excl[dk] + s_whist[w][dk] + rank[k];
-            s_keys[slot] = key[k];
-            s_vals[slot] = val[k];
+            slot[k] = (uint16_t)(s_excl[dk] + s_whist[w][dk] + slot[k]);
+            s_stage[slot[k]] = key[k];
         }
     }
     OS_STAMP(2);
 
     // decoupled look-back, a WINDOW of predecessors per memory round trip
-    {
+    if (digit_thread) {
         uint32_t before = 0;                                   // digit d in tiles [0, tile)
         bool failed = false;
         uint32_t hops = 0, total_spins = 0;
-        constexpr int kWin = 8;
+        constexpr int kWin = GPE_OS_WIN;
         bool done = (tile == 0);
         for (int64_t t = (int64_t)tile - 1; !done && !failed; t -= kWin) {
             u64 sw[kWin];
@@ -242,15 +271,33 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *__restrict
         s_delta[d] = bases4[pass * 256 + d] + before - s_excl[d];
     }
     __syncthreads();
-    OS_STAMP(1 + 0 * 2);
-    for (uint32_t j = threadIdx.x; j < tile_n; j += kOsBlock) {
-        const uint32_t kk = s_keys[j];
-        const uint32_t d = (kk >> shift) & 255u;
-        const uint32_t dst = s_delta[d] + j;
-        keys_out[dst] = kk;
-        vals_out[dst] = s_vals[j];
-    }
     OS_STAMP(3);
+
+    // write-out: slot j of digit d goes to s_delta[d] + j -- each digit's run is one contiguous store
+    uint32_t dst[kOsItems];
+#pragma unroll
+    for (int q = 0; q < kOsItems; ++q) {
+        const uint32_t j = threadIdx.x + (uint32_t)q * kOsBlock;
+        dst[q] = 0;
+        if (j < tile_n) {
+            const uint32_t kk = s_stage[j];
+            dst[q] = s_delta[(kk >> shift) & 255u] + j;
+            keys_out[dst[q]] = kk;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kOsItems; ++k) {
+        const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
+        if (idx < n) s_stage[slot[k]] = val[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kOsItems; ++q) {
+        const uint32_t j = threadIdx.x + (uint32_t)q * kOsBlock;
+        if (j < tile_n) vals_out[dst[q]] = s_stage[j];
+    }
+    OS_STAMP(4);
 }
 
 static uint64_t os_tiles(uint64_t n) { return (n + kOsTile - 1) / kOsTile; }
@@ -307,7 +354,7 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
     if (!hist_ready) {
         Scope s(c, "sort/hist");
         GPE_TRY(onesweep_zero_hist(c));
-        hipLaunchKernelGGL(k_os_hist4, dim3(stream_grid(n, kOsBlock)), dim3(kOsBlock), 0, c->stream, keys, n,
+        hipLaunchKernelGGL(k_os_hist4, dim3(stream_grid(n, kStreamBlock)), dim3(kStreamBlock), 0, c->stream, keys, n,
                            ws.hist4);
         GPE_HIP(c, hipGetLastError());
     }
@@ -346,9 +393,9 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
             (void)hipStreamSynchronize(c->stream);
             (void)hipMemcpy(h, ws.ctl, sizeof(h), hipMemcpyDeviceToHost);
             const double nt = h[26] ? (double)h[26] : 1.0;
-            fprintf(stderr, "[os stamps] n=%llu passes=%d sampled=%u  load %.0f  rank %.0f  lookback %.0f  reorder+write %.0f cyc;"
+            fprintf(stderr, "[os stamps] n=%llu passes=%d sampled=%u  load %.0f  rank %.0f  reorder %.0f  lookback %.0f  write %.0f cyc;"
                             " hops/tile %.1f spins/tile %.1f\n", (unsigned long long)n, passes, h[26], h[16] / nt, h[17] / nt,
-                    h[18] / nt, h[19] / nt, h[24] / nt, h[25] / nt);
+                    h[18] / nt, h[19] / nt, h[20] / nt, h[24] / nt, h[25] / nt);
         }
         (void)hipMemsetAsync(ws.ctl + 16, 0, 16 * sizeof(uint32_t), c->stream);
     }
