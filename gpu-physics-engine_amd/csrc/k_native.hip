@@ -29,6 +29,9 @@
 #ifndef GPE_NAT_THREADS
 #define GPE_NAT_THREADS 512
 #endif
+#ifndef GPE_P5_PRIO
+#define GPE_P5_PRIO 0
+#endif
 
 namespace gpe {
 
@@ -551,6 +554,11 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     GPE_STAMP(4);
 
     // ---- P5: the four colour passes (collision_solver.rs:224), one lane per collision cell ----------
+    // The colour passes are one long dependent chain per cell (sqrt, divisions, LDS round trips): give these
+    // waves issue priority over the other tiles' throughput phases that share the SIMD.
+#if GPE_P5_PRIO
+    __builtin_amdgcn_s_setprio(GPE_P5_PRIO);
+#endif
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const uint32_t nk = S.lcnt[k];
@@ -565,6 +573,9 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
 #endif
         __syncthreads();
     }
+#if GPE_P5_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     GPE_STAMP(5);
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
