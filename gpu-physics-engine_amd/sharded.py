@@ -278,87 +278,106 @@ class ShardedState:
 
     # -- one step --------------------------------------------------------------------------------------
     def exchange(self):
-        """Migrate particles that left this rank's blocks, then (re)build the ghost layer."""
-        e, rank = self.e, self.rank
+        """Migrate particles that left this rank's blocks, then (re)build the ghost layer.
+        Written to need two host syncs only (the classify count and the count matrix): no boolean-mask
+        indexing -- the (peer, kind) groups come from one sort, their sizes from the gathered counts."""
+        e, rank, ws = self.e, self.rank, self.ws
+        dev = e.device
         with e.stream_ctx():
             a = e.arrays()
             e.set_counts(max(self.n_owned, 1), self.n_owned)               # ghosts of the last step are gone
-            idx, info = e.classify(self.dec, rank, self.tables)
+            idx, info = e.classify(self.dec, rank, self.tables)            # host sync 1: k boundary particles
+            k = int(idx.numel())
+            peers = torch.arange(ws, device=dev, dtype=info.dtype)
             owner1 = (info >> 26) & 31                                     # 1 + new owner, 0 = stays here
             mask = info & 0x03FFFFFF                                       # ranks bordering its current block
-            is_mig = owner1 > 0
-            mig_idx, mig_owner = idx[is_mig], owner1[is_mig].long() - 1
-            mine = torch.zeros((self.ws, 2), dtype=torch.int64, device=e.device)
+            # kind 0: migrant to `peer`; kind 1: ghost for `peer` (a migrant is a ghost for every bordering rank
+            # except its new owner, including this rank itself: it stays behind as one of its own ghosts)
+            mig = owner1[:, None] == peers[None, :] + 1                                        # [k, ws]
+            gho = (((mask[:, None] >> peers[None, :]) & 1) != 0) & ~mig                        # [k, ws]
+            sel = torch.stack([mig, gho], 0)                                                   # [2, k, ws]
+            mine = sel.sum(1).to(torch.int64).t().contiguous()                                 # [ws, 2]
+            counts = self._gather_counts(mine).cpu()                       # host sync 2: [src, dst, 2]
+            cm = [int(counts[rank, p, 0]) for p in range(ws)]              # migrants I send to p
+            cg = [int(counts[rank, p, 1]) for p in range(ws)]              # ghosts I send to p (p == rank: local)
+            total = sum(cm) + sum(cg)
             send = {}
-            gid_f = a["gid"].view(torch.float32)
-
-            def ghost_rows(gi):
-                return torch.cat([a["pos"][gi], a["radius"][gi, None], gid_f[gi, None]], 1)
-
-            for peer in range(self.ws):
-                if peer == rank:
-                    continue
-                mi = mig_idx[mig_owner == peer]
-                # ghosts for `peer`: everything in a block bordering it -- a migrant included, unless `peer`
-                # is the migrant's new owner (it then arrives as an owned particle)
-                gi = idx[(((mask >> peer) & 1) != 0) & (owner1 != peer + 1)]
-                if mi.numel() + gi.numel() == 0:
-                    continue
-                mine[peer, 0], mine[peer, 1] = mi.numel(), gi.numel()
-                mrows = torch.cat([a["pos"][mi], a["prev"][mi], a["radius"][mi, None], gid_f[mi, None]], 1).reshape(-1)
-                send[peer] = torch.cat([mrows, ghost_rows(gi).reshape(-1)]).contiguous()
-            # a migrant that still borders this rank stays behind as one of its own ghosts
-            local_ghosts = ghost_rows(idx[is_mig & (((mask >> rank) & 1) != 0)]).clone()
-            counts = self._gather_counts(mine).cpu()
+            local_ghosts = None
+            n_mig = sum(cm)
+            holes = None
+            if total:
+                # group the selected (kind, peer, entry) triples: key = kind * ws + peer, entries in index order
+                key = torch.arange(2 * ws, device=dev).view(2, 1, ws).expand(2, k, ws)
+                key = torch.where(sel, key, torch.full_like(key, 4 * ws)).permute(0, 2, 1).reshape(-1)   # [2*ws*k]
+                order = torch.argsort(key, stable=True)[:total]
+                src = idx[order % k]                                       # local particle of every triple
+                gid_f = a["gid"].view(torch.float32)
+                rows = torch.cat([a["pos"][src], a["prev"][src], a["radius"][src, None], gid_f[src, None]], 1)
+                holes = src[:n_mig]
+                off_m = np.concatenate([[0], np.cumsum(cm)])
+                off_g = n_mig + np.concatenate([[0], np.cumsum(cg)])
+                for p in range(ws):
+                    g_rows = rows[off_g[p]:off_g[p + 1]][:, [0, 1, 4, 5]]
+                    if p == rank:
+                        local_ghosts = g_rows.clone()
+                        continue
+                    if cm[p] + cg[p]:
+                        send[p] = torch.cat([rows[off_m[p]:off_m[p + 1]].reshape(-1), g_rows.reshape(-1)]).contiguous()
             recv = self._exchange(send, counts)
 
-            # drop the migrants: fill their holes from the tail (order is free: members sort by order key)
-            k = int(mig_idx.numel())
-            if k:
-                n0 = self.n_owned
-                holes = torch.sort(mig_idx).values
-                tail = torch.arange(n0 - k, n0, device=e.device)
-                tail_keep = tail[~torch.isin(tail, holes)]
-                holes_front = holes[holes < n0 - k]
-                for name in ("pos", "prev", "radius", "gid"):
-                    a[name][holes_front] = a[name][tail_keep]
-                self.n_owned = n0 - k
-            # arrivals: migrants become owned, ghosts follow all owned particles
-            arr_m = [(p, int(counts[p, rank, 0])) for p in sorted(recv)]
-            n_in = sum(c for _, c in arr_m)
-            n_gh = sum(int(counts[p, rank, 1]) for p in recv) + int(local_ghosts.shape[0])
-            self._ensure_capacity(self.n_owned + n_in + n_gh + 1)
+            n_in = sum(int(counts[p, rank, 0]) for p in range(ws) if p != rank)
+            n_gh = sum(int(counts[p, rank, 1]) for p in range(ws) if p != rank) + cg[rank]
+            self._ensure_capacity(self.n_owned - n_mig + n_in + n_gh + 2)
             a = e.arrays()
+            # drop the migrants: fill their holes from the tail (order is free: members sort by order key).
+            # Fixed-length formulation (no sync): the i-th hole in front of the tail takes the i-th tail survivor;
+            # the unused pairs copy a spare slot onto itself.
+            if n_mig:
+                n0 = self.n_owned
+                spare = e.capacity() - 1
+                hs = torch.sort(holes).values
+                tail = torch.arange(n0 - n_mig, n0, device=dev)
+                tail_is_hole = torch.isin(tail, hs)
+                survivors = tail[torch.argsort(tail_is_hole.to(torch.int8), stable=True)]
+                n_move = (~tail_is_hole).sum()
+                lanes = torch.arange(n_mig, device=dev)
+                dst = torch.where((hs < n0 - n_mig) & (lanes < n_move), hs, torch.full_like(hs, spare))
+                srcm = torch.where(lanes < n_move, survivors, torch.full_like(survivors, spare))
+                for name in ("pos", "prev", "radius", "gid"):
+                    a[name][dst] = a[name][srcm]
+                self.n_owned = n0 - n_mig
+            # arrivals: migrants become owned, ghosts follow all owned particles
             o = self.n_owned
-            for p, c in arr_m:
+            for p in sorted(recv):
+                c = int(counts[p, rank, 0])
                 if c:
-                    rows = recv[p][:c * 6].view(c, 6)
-                    a["pos"][o:o + c] = rows[:, 0:2]
-                    a["prev"][o:o + c] = rows[:, 2:4]
-                    a["radius"][o:o + c] = rows[:, 4]
-                    a["gid"][o:o + c] = rows[:, 5].contiguous().view(torch.int32)
+                    r6 = recv[p][:c * 6].view(c, 6)
+                    a["pos"][o:o + c] = r6[:, 0:2]
+                    a["prev"][o:o + c] = r6[:, 2:4]
+                    a["radius"][o:o + c] = r6[:, 4]
+                    a["gid"][o:o + c] = r6[:, 5].contiguous().view(torch.int32)
                     o += c
             self.n_owned = o
             for p in sorted(recv):
-                cm, cg = int(counts[p, rank, 0]), int(counts[p, rank, 1])
-                if cg:
-                    rows = recv[p][cm * 6:cm * 6 + cg * 4].view(cg, 4)
-                    a["pos"][o:o + cg] = rows[:, 0:2]
-                    a["radius"][o:o + cg] = rows[:, 2]
-                    a["gid"][o:o + cg] = rows[:, 3].contiguous().view(torch.int32)
-                    o += cg
-            cg = int(local_ghosts.shape[0])
-            if cg:
-                a["pos"][o:o + cg] = local_ghosts[:, 0:2]
-                a["radius"][o:o + cg] = local_ghosts[:, 2]
-                a["gid"][o:o + cg] = local_ghosts[:, 3].contiguous().view(torch.int32)
-                o += cg
+                c0, c = int(counts[p, rank, 0]), int(counts[p, rank, 1])
+                if c:
+                    r4 = recv[p][c0 * 6:c0 * 6 + c * 4].view(c, 4)
+                    a["pos"][o:o + c] = r4[:, 0:2]
+                    a["radius"][o:o + c] = r4[:, 2]
+                    a["gid"][o:o + c] = r4[:, 3].contiguous().view(torch.int32)
+                    o += c
+            if local_ghosts is not None and cg[rank]:
+                c = cg[rank]
+                a["pos"][o:o + c] = local_ghosts[:, 0:2]
+                a["radius"][o:o + c] = local_ghosts[:, 2]
+                a["gid"][o:o + c] = local_ghosts[:, 3].contiguous().view(torch.int32)
+                o += c
             self.n_ghost = o - self.n_owned
             if self.n_owned == 0:
                 raise RuntimeError("rank %d owns no particle any more (unsupported)" % rank)
             e.n_owned = self.n_owned
             e.set_counts(self.n_owned + self.n_ghost, self.n_owned)
-            self.stats["migrants"] += k
+            self.stats["migrants"] += n_mig
             self.stats["ghosts"] += self.n_ghost
 
     def resort(self):
