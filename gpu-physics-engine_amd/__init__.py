@@ -12,6 +12,10 @@ from .engine import (Context, GpuBuffer, ParticleSystem, Grid, CollisionSystem, 
                      PrefixSum, State, NUM_BLOCKS_PER_WORKGROUP, RADIX_SORT_BUCKETS)
 
 
-def build(force=False):
-    from .build import build_library
+def _build_library(force=False):
+    from .build import build_library       # importing the submodule rebinds the package attribute `build` ...
+    globals()["build"] = _build_library    # ... so put the callable back
     return build_library(force=force)
+
+
+build = _build_library

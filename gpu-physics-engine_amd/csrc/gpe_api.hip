@@ -408,7 +408,7 @@ static gpe_status check_device_errors(gpe_ctx *c)
 {
     uint32_t words[2] = {0, 0};
     if (c->native.tile_ctl)
-        GPE_HIP(c, hipMemcpyAsync(&words[0], c->native.tile_ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
+        GPE_HIP(c, hipMemcpyAsync(&words[0], c->native.tile_ctl + 8, 4, hipMemcpyDeviceToHost, c->stream));
     if (c->os_ws.ctl)
         GPE_HIP(c, hipMemcpyAsync(&words[1], c->os_ws.ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));

@@ -200,7 +200,11 @@ struct NativeState {
     uint32_t *tile_ctl = nullptr;    // device control words (k_native.hip kCtl*)
     uint32_t *overflow1 = nullptr;   // packed (ty << 16 | tx) of 32x32 tiles over capacity
     uint32_t *overflow2 = nullptr;   // ... of 16x16 tiles over capacity (4x as many slots)
+    uint32_t *overflow3 = nullptr;   // ... of 8x8 tiles over the LDS capacity (16x as many slots)
     uint64_t overflow_cap = 0;
+    void *arena = nullptr;           // global spill arena for those tiles' particle arrays (37 B per slot)
+    uint64_t arena_cap = 0;          // slots
+    bool force = false;              // GPE_NATIVE_FORCE=1 (tests): no hand-over to the compat kernels
     uint32_t *host_stat = nullptr;   // pinned: [0] last reported max 24x24-cell window population
     uint32_t window_max = 0;         // the same, measured synchronously at configuration time
     bool dense_hold = false;         // left the native path because windows were filling up

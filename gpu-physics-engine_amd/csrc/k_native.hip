@@ -21,6 +21,7 @@
 // barrier is needed.  Positions are double-buffered (read pos_in, write pos_out) because neighbours
 // read a tile's step-start positions while it writes its results.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -65,7 +66,11 @@ constexpr uint32_t kErrRegion = 4u;            // internal: particle outside its
 constexpr int kCtlOverflow1 = 0;               // 32x32 tiles over capacity this step
 constexpr int kCtlOverflow2 = 1;               // 16x16 tiles over capacity this step
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
-constexpr int kCtlError = 4;
+constexpr int kCtlArena = 3;                   // particles handed out of the global spill arena this step
+constexpr int kCtlOverflow3 = 4;               // 8x8 tiles over the LDS capacity this step (-> global arena)
+constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every step
+constexpr int kCtlError = 8;                   // sticky
+constexpr uint64_t kArenaBytesPerSlot = 37;    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
 constexpr int kTileMain = 32, kCapMain = 960;
 constexpr int kTileMid = 16, kCapMid = 1920;
@@ -192,6 +197,13 @@ struct CollideArgs {
     uint32_t overflow1_cap;
     uint32_t *overflow2;         // ... of over-capacity 16x16 tiles
     uint32_t overflow2_cap;
+    uint32_t *overflow3;         // ... of 8x8 tiles over the LDS capacity: staged in the global arena instead
+    uint32_t overflow3_cap;
+    // spill arena (global memory) for the particle arrays of such tiles
+    float *arena_px, *arena_py, *arena_rad;
+    uint32_t *arena_id, *arena_hm, *arena_mem;   // arena_mem holds 4 entries per particle
+    uint8_t *arena_sblk;
+    uint32_t arena_cap;
     unsigned long long *stamps;  // diagnostic builds only (-DGPE_TILE_STAMPS): cycles per phase, thread 0
 };
 
@@ -213,6 +225,8 @@ struct CollideArgs {
 
 template <int T, int CAP>
 struct TileLds {
+    static constexpr int TILE = T;
+    static constexpr bool kGlobal = false;
     static constexpr int RW = T + 2 * kHalo;
     static constexpr int NCELL = RW * RW;
     static constexpr int NB = RW / 8;
@@ -240,28 +254,55 @@ struct TileLds {
     uint32_t misc[4];
 };
 
+// Same window, but the per-particle arrays live in a slice of the global spill arena: for 8x8 tiles whose
+// 24x24-cell region holds more particles than any LDS window stages (thousands of particles piled into a few
+// cells).  Slow and rare; it exists so that the native path is exact for every input, not only for sparse ones.
+template <int T>
+struct TileGlobal {
+    static constexpr int TILE = T;
+    static constexpr bool kGlobal = true;
+    static constexpr int RW = T + 2 * kHalo;
+    static constexpr int NCELL = RW * RW;
+    static constexpr int NB = RW / 8;
+    static constexpr int NBLK = NB * NB;
+    static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;
+    static constexpr int QMAX = 1;
+    static constexpr int QZ = (T + 8) * (T + 8) / 4;
+    float *px, *py, *rad;
+    uint32_t *id, *hm, *mem;
+    uint8_t *sblk;
+    uint32_t cell[NCELL + 1];
+    uint16_t list[4 * QZ];
+    uint32_t lcnt[4];
+    uint32_t bstart[NBLK];
+    uint32_t bcnt[NBLK];
+    uint32_t boff[NBLK + 1];
+    uint32_t s_w[16];
+    uint32_t misc[4];
+};
+
 // Members of one cell into ascending object index (the order the reference's stable sort gives them).
 template <class L>
 __device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint32_t e)
 {
     const uint32_t n = e - b;
     if (n == 2) {
-        const uint16_t m0 = S.mem[b], m1 = S.mem[b + 1];
+        const uint32_t m0 = S.mem[b], m1 = S.mem[b + 1];
         if (S.id[m0] > S.id[m1]) { S.mem[b] = m1; S.mem[b + 1] = m0; }
         return;
     }
     if (n == 3) {
-        uint16_t m0 = S.mem[b], m1 = S.mem[b + 1], m2 = S.mem[b + 2];
+        uint32_t m0 = S.mem[b], m1 = S.mem[b + 1], m2 = S.mem[b + 2];
         uint32_t i0 = S.id[m0], i1 = S.id[m1], i2 = S.id[m2];
         bool ch = false;
-        if (i0 > i1) { uint16_t t = m0; m0 = m1; m1 = t; uint32_t u = i0; i0 = i1; i1 = u; ch = true; }
-        if (i1 > i2) { uint16_t t = m1; m1 = m2; m2 = t; uint32_t u = i1; i1 = i2; i2 = u; ch = true; }
-        if (i0 > i1) { uint16_t t = m0; m0 = m1; m1 = t; ch = true; }
+        if (i0 > i1) { uint32_t t = m0; m0 = m1; m1 = t; uint32_t u = i0; i0 = i1; i1 = u; ch = true; }
+        if (i1 > i2) { uint32_t t = m1; m1 = m2; m2 = t; uint32_t u = i1; i1 = i2; i2 = u; ch = true; }
+        if (i0 > i1) { uint32_t t = m0; m0 = m1; m1 = t; ch = true; }
         if (ch) { S.mem[b] = m0; S.mem[b + 1] = m1; S.mem[b + 2] = m2; }
         return;
     }
     for (uint32_t i = b + 1; i < e; ++i) {                             // insertion sort
-        const uint16_t x = S.mem[i];
+        const uint32_t x = S.mem[i];
         const uint32_t kx = S.id[x];
         uint32_t j = i;
         while (j > b && S.id[S.mem[j - 1]] > kx) { S.mem[j] = S.mem[j - 1]; --j; }
@@ -318,11 +359,11 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
     }
 }
 
-// One tile: returns false when the region exceeds the LDS capacity (nothing written).
-template <int T, int CAP>
-__device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int tx, const int ty)
+// One tile: returns false when the region exceeds the window's capacity (nothing written).
+template <class L>
+__device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
 {
-    using L = TileLds<T, CAP>;
+    constexpr int T = L::TILE;
     constexpr int RW = L::RW, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
     static_assert(NBLK <= 255, "sblk is 8 bit");
     const int tid = (int)threadIdx.x;
@@ -379,7 +420,21 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
     __syncthreads();
     const uint32_t P = S.misc[0];
     if (S.misc[1] == 0) return true;                                   // nothing of its own to write
-    if (P > (uint32_t)CAP) return false;
+    if constexpr (L::kGlobal) {
+        // take a slice of the global spill arena for this tile's particle arrays
+        if (tid == 0) {
+            const uint32_t base = atomicAdd(&A.tile_ctl[kCtlArena], P);
+            const bool ok = (uint64_t)base + P <= (uint64_t)A.arena_cap;
+            S.misc[2] = ok ? 1u : 0u;
+            S.px = A.arena_px + base; S.py = A.arena_py + base; S.rad = A.arena_rad + base;
+            S.id = A.arena_id + base; S.hm = A.arena_hm + base; S.sblk = A.arena_sblk + base;
+            S.mem = A.arena_mem + 4ull * base;
+        }
+        __syncthreads();
+        if (S.misc[2] == 0) return false;
+    } else {
+        if (P > (uint32_t)(sizeof(S.px) / sizeof(float))) return false;
+    }
     {
         // slot -> block map: kNatThreads / NBLK threads share each block's slots
         constexpr int SHARE = (kNatThreads / NBLK) > 0 ? (kNatThreads / NBLK) : 1;
@@ -393,13 +448,13 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
 
     // ---- P1: gather the region's particles (all loads of a thread in flight together), count the
     //          cell memberships -----------------------------------------------------------------------
-    {
+    for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QMAX * kNatThreads) {   // one round unless the window spills
         uint32_t pid[QMAX];
         float2 pp[QMAX];
         float pr[QMAX];
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
-            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             pid[q] = 0;
             if (s < P) {
                 const uint32_t b = S.sblk[s];
@@ -412,7 +467,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
 #endif
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
-            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             pp[q] = make_float2(0.f, 0.f);
             pr[q] = 0.f;
             if (s < P) {
@@ -429,7 +484,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
 #endif
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
-            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             if (s >= P) continue;
             const float2 p = pp[q];
             const float r = pr[q];
@@ -500,7 +555,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
         const uint32_t hm = S.hm[s];
         const int home = (int)(hm & 0xFFFFu);
         uint32_t k = atomicAdd(&S.cell[home + 1], 1u);
-        S.mem[k] = (uint16_t)s;
+        S.mem[k] = s;
         const uint32_t pc = hm >> 28;
         const int lx = home % RW, ly = home / RW;
         for (uint32_t q = 0; q < pc; ++q) {
@@ -509,7 +564,7 @@ __device__ bool process_tile(TileLds<T, CAP> &S, const CollideArgs &A, const int
             if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) {
                 const int lc = nly * RW + nlx;
                 k = atomicAdd(&S.cell[lc + 1], 1u);
-                S.mem[k] = (uint16_t)s;
+                S.mem[k] = s;
             }
         }
     }
@@ -612,7 +667,7 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
     const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
-    if (!process_tile<T, CAP>(S, A, tx, ty)) {
+    if (!process_tile(S, A, tx, ty)) {
         if (threadIdx.x == 0) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
             if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
@@ -621,34 +676,36 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     }
 }
 
-// Levels 1 and 2: the over-capacity parents (edge 2T) of the previous level are redone as four tiles of
-// edge T by a fixed grid that strides over the device-side list (HIP has no indirect dispatch).
-// LEVEL 1 reads overflow1 and spills to overflow2; LEVEL 2 reads overflow2 and has nowhere to spill.
-template <int T, int CAP, int LEVEL>
+// Levels 1-3: the over-capacity tiles of the previous level are redone by a fixed grid that strides over the
+// device-side list (HIP has no indirect dispatch).  LEVEL 1: 32x32 parents as four 16x16 tiles; LEVEL 2: 16x16
+// parents as four 8x8 tiles; LEVEL 3: 8x8 tiles again, with their particle arrays in the global spill arena.
+template <class L, int LEVEL>
 __global__ __launch_bounds__(kNatThreads) void k_collide_sublist(CollideArgs A)
 {
-    __shared__ TileLds<T, CAP> S;
-    const uint32_t *list = (LEVEL == 1) ? A.overflow1 : A.overflow2;
-    const uint32_t cap = (LEVEL == 1) ? A.overflow1_cap : A.overflow2_cap;
-    uint32_t count = A.tile_ctl[(LEVEL == 1) ? kCtlOverflow1 : kCtlOverflow2];
+    __shared__ L S;
+    constexpr uint32_t SPLIT = (LEVEL == 3) ? 1u : 2u;
+    const uint32_t *list = (LEVEL == 1) ? A.overflow1 : (LEVEL == 2) ? A.overflow2 : A.overflow3;
+    const uint32_t cap = (LEVEL == 1) ? A.overflow1_cap : (LEVEL == 2) ? A.overflow2_cap : A.overflow3_cap;
+    uint32_t count = A.tile_ctl[(LEVEL == 1) ? kCtlOverflow1 : (LEVEL == 2) ? kCtlOverflow2 : kCtlOverflow3];
     if (count > cap) count = cap;
-    const uint32_t work = count * 4u;
+    const uint32_t work = count * SPLIT * SPLIT;
     for (uint32_t i = blockIdx.x; i < work; i += gridDim.x) {
-        const uint32_t parent = list[i >> 2];
-        const int sub = (int)(i & 3u);
-        const int tx = (int)(parent & 0xFFFFu) * 2 + (sub & 1), ty = (int)(parent >> 16) * 2 + (sub >> 1);
-        if (process_tile<T, CAP>(S, A, tx, ty)) continue;
-        if (LEVEL == 1) {
+        const uint32_t parent = list[i / (SPLIT * SPLIT)];
+        const uint32_t sub = i % (SPLIT * SPLIT);
+        const int tx = (int)((parent & 0xFFFFu) * SPLIT + sub % SPLIT), ty = (int)((parent >> 16) * SPLIT + sub / SPLIT);
+        if (process_tile(S, A, tx, ty)) continue;
+        if (LEVEL < 3) {
+            uint32_t *out = (LEVEL == 1) ? A.overflow2 : A.overflow3;
+            const uint32_t out_cap = (LEVEL == 1) ? A.overflow2_cap : A.overflow3_cap;
             if (threadIdx.x == 0) {
-                const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow2], 1u);
-                if (slot < A.overflow2_cap) A.overflow2[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+                const uint32_t slot = atomicAdd(&A.tile_ctl[(LEVEL == 1) ? kCtlOverflow2 : kCtlOverflow3], 1u);
+                if (slot < out_cap) out[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
                 else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
             }
         } else {
-            // No smaller window exists: flag it (gpe_sync / gpe_download report the error) and pass the
-            // tile's own particles through unresolved so that the state stays finite.
+            // the spill arena is exhausted: flag it (gpe_sync / gpe_download report the error) and pass the
+            // tile's own particles through unresolved so that the state stays finite
             if (threadIdx.x == 0) atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
-            using L = TileLds<T, CAP>;
             for (int b = threadIdx.x; b < L::NBLK; b += kNatThreads) {
                 const int bi = b % L::NB, bj = b / L::NB;
                 if (bi < 1 || bi >= L::NB - 1 || bj < 1 || bj >= L::NB - 1) continue;
@@ -686,6 +743,8 @@ void native_release(gpe_ctx *c)
     if (N.tile_ctl) (void)hipFree(N.tile_ctl);
     if (N.overflow1) (void)hipFree(N.overflow1);
     if (N.overflow2) (void)hipFree(N.overflow2);
+    if (N.overflow3) (void)hipFree(N.overflow3);
+    if (N.arena) (void)hipFree(N.arena);
     if (N.host_stat) (void)hipHostFree(N.host_stat);
     N = NativeState();
 }
@@ -695,7 +754,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
 {
     NativeState &N = c->native;
     const uint64_t n = c->n;
-    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 16, c->stream));         // per-step words; the error word stays
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, kCtlPerStepWords * 4, c->stream));   // the error word stays
     GPE_HIP(c, hipMemsetAsync(N.block_table, 0, (size_t)N.table_entries * sizeof(uint2), c->stream));
     GPE_TRY(onesweep_zero_hist(c));
     {
@@ -764,10 +823,23 @@ gpe_status native_configure(gpe_ctx *c)
     if (N.overflow_cap < tiles) {
         if (N.overflow1) GPE_HIP(c, hipFree(N.overflow1));
         if (N.overflow2) GPE_HIP(c, hipFree(N.overflow2));
-        N.overflow1 = N.overflow2 = nullptr; N.overflow_cap = 0;
+        if (N.overflow3) GPE_HIP(c, hipFree(N.overflow3));
+        N.overflow1 = N.overflow2 = N.overflow3 = nullptr; N.overflow_cap = 0;
         GPE_HIP(c, hipMalloc((void **)&N.overflow1, (tiles + 16) * sizeof(uint32_t)));
         GPE_HIP(c, hipMalloc((void **)&N.overflow2, (4 * tiles + 16) * sizeof(uint32_t)));
+        GPE_HIP(c, hipMalloc((void **)&N.overflow3, (16 * tiles + 16) * sizeof(uint32_t)));
         N.overflow_cap = tiles;
+    }
+    {
+        // spill arena: every particle can be staged by the 9 windows around it, but a scene that dense has
+        // left the native path long before (native_should_run); one slot per particle, 1 M .. 32 M slots
+        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, 1ull << 20), 32ull << 20);
+        if (N.arena_cap < want) {
+            if (N.arena) GPE_HIP(c, hipFree(N.arena));
+            N.arena = nullptr; N.arena_cap = 0;
+            GPE_HIP(c, hipMalloc(&N.arena, want * kArenaBytesPerSlot + 256));
+            N.arena_cap = want;
+        }
     }
     if (!N.tile_ctl) GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, 64));
     if (!N.host_stat) GPE_HIP(c, hipHostMalloc((void **)&N.host_stat, 64, hipHostMallocDefault));
@@ -798,6 +870,10 @@ gpe_status native_configure(gpe_ctx *c)
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
     N.window_max = wmax;
     N.eligible = wmax <= (uint32_t)kCapSmall;
+    // test hook: keep over-dense scenes on the native kernels (their windows then go through the spill arena)
+    const char *force = getenv("GPE_NATIVE_FORCE");
+    N.force = force && force[0] == '1';
+    if (N.force) N.eligible = true;
     return GPE_OK;
 }
 
@@ -810,7 +886,7 @@ bool native_should_run(gpe_ctx *c)
     NativeState &N = c->native;
     if (c->cfg.mode != GPE_MODE_NATIVE) return false;
     if (N.eligible) {
-        if (N.host_stat && N.host_stat[0] > (uint32_t)(kCapSmall / 4 * 3)) {
+        if (!N.force && N.host_stat && N.host_stat[0] > (uint32_t)(kCapSmall / 4 * 3)) {
             N.eligible = false;
             N.dense_hold = true;
             N.steps_since_check = 0;
@@ -848,6 +924,18 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     A.overflow1_cap = (uint32_t)N.overflow_cap;
     A.overflow2 = N.overflow2;
     A.overflow2_cap = (uint32_t)(4 * N.overflow_cap);
+    A.overflow3 = N.overflow3;
+    A.overflow3_cap = (uint32_t)(16 * N.overflow_cap);
+    {
+        // arena layout: px | py | rad | id | hm | mem (4 per slot) | sblk
+        float *f = (float *)N.arena;
+        const uint64_t m = N.arena_cap;
+        A.arena_px = f; A.arena_py = f + m; A.arena_rad = f + 2 * m;
+        A.arena_id = (uint32_t *)(f + 3 * m); A.arena_hm = (uint32_t *)(f + 4 * m);
+        A.arena_mem = (uint32_t *)(f + 5 * m);
+        A.arena_sblk = (uint8_t *)(f + 9 * m);
+        A.arena_cap = (uint32_t)m;
+    }
     A.order_keys = c->use_order_keys ? c->order_keys : nullptr;
     A.tile_x0 = A.tile_y0 = 0;
     A.stamps = nullptr;
@@ -886,10 +974,15 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     {
         // tiles whose 48x48-cell region exceeded the LDS capacity: 16x16 tiles, then 8x8 tiles
         Scope s(c, "native/collide-dense-regions");
-        hipLaunchKernelGGL((k_collide_sublist<kTileMid, kCapMid, 1>), dim3(512), dim3(kNatThreads), 0, c->stream, A);
+        hipLaunchKernelGGL((k_collide_sublist<TileLds<kTileMid, kCapMid>, 1>), dim3(512), dim3(kNatThreads), 0,
+                           c->stream, A);
         GPE_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL((k_collide_sublist<kTileSmall, kCapSmall, 2>), dim3(512), dim3(kNatThreads), 0, c->stream,
-                           A);
+        hipLaunchKernelGGL((k_collide_sublist<TileLds<kTileSmall, kCapSmall>, 2>), dim3(512), dim3(kNatThreads), 0,
+                           c->stream, A);
+        GPE_HIP(c, hipGetLastError());
+        // 8x8 tiles whose 24x24-cell window exceeds the LDS capacity: particle arrays in the global arena
+        hipLaunchKernelGGL((k_collide_sublist<TileGlobal<kTileSmall>, 3>), dim3(256), dim3(kNatThreads), 0,
+                           c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
     GPE_HIP(c, hipMemcpyAsync(N.host_stat, N.tile_ctl + kCtlWindowMax, sizeof(uint32_t), hipMemcpyDeviceToHost,

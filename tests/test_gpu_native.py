@@ -170,3 +170,40 @@ def test_native_add_particles(gpe, oracle):
         st.update(1 / 60, resort=(s == 3)); sim.step(1 / 60, resort=(s == 3))
     _assert_positions(st.positions(), sim.pos, "positions after add_particles (native)")
     st.close(); sim.close()
+
+
+def test_native_spill_arena_is_exact(gpe, oracle, monkeypatch):
+    """GPE_NATIVE_FORCE=1 keeps an over-dense scene on the native kernels: every 8x8 tile overflows the LDS
+    windows and is resolved with its particle arrays in the global spill arena -- same bits as the oracle."""
+    monkeypatch.setenv("GPE_NATIVE_FORCE", "1")
+    n = 12_000
+    world = (33.0, 33.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=12)
+    st = _native(gpe, pos, rad, world)
+    st.ctx.set_profiling(True)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    for s in range(3):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+    _assert_positions(st.positions(), sim.pos, "over-dense scene through the spill arena")
+    st.ctx.sync()
+    assert st.ctx.timings()["native/collide"][1] == 3
+    st.close(); sim.close()
+
+
+def test_native_mouse_blob_hands_over_without_error(gpe):
+    """Mouse attraction packs the cloud into a blob while steps are in flight: windows that overfill before the
+    (lagged) density statistic moves the context to the compat kernels spill to the arena.  Never an error, and
+    the same bits as a compat-only run."""
+    n = 60_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=9)
+    a = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    b = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
+    for st in (a, b):
+        st.particles.mouse_click_callback(True, (world[0] * 0.5, world[1] * 0.5))
+    for chunk in range(8):
+        a.run(1 / 60, 100, resort_every=240, resort_first=(chunk == 0))
+        b.run(1 / 60, 100, resort_every=240, resort_first=(chunk == 0))
+        assert np.array_equal(a.positions(), b.positions()), "after %d steps" % ((chunk + 1) * 100)
+    a.ctx.sync()
+    a.close(); b.close()
