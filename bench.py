@@ -29,6 +29,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALGO_BYTES_PER_PARTICLE = 148    # hash 12 + sort 68 + grid 8 + collision 24 + integrate 36
 RESORT_EVERY = 240               # 4 s at 60 Hz (particle_system.rs:13-14)
+PROFILE_EVERY = 10               # kernels of every 10th timed step are bracketed by HIP events (an event pair
+                                 # per kernel on every step costs ~35% at 1M particles)
 
 
 def log(*a):
@@ -63,6 +65,9 @@ def kernel_rooflines(timings, n_particles, mode):
         "native/hash": (12 * n, "R pos 8 B, W cell key 4 B per particle"),
         "native/table": (8 * n, "R sorted key 4 B, W block bounds ~4 B per particle"),
         "native/collide": (24 * n, "R pos 8 + radius 4 + id 4, W pos 8 per particle (SURVEY 8d collision row)"),
+        "native/collide+verlet": (40 * n, "collision row (R pos 8 + radius 4 + id 4, W pos 8) + fused integration "
+                                          "(R prev 8, W prev 8) per particle"),
+        "native/clear": (0 * n + 1, "zeroes the block table (8 B per 64 cells) + histograms"),
         "Build cell ids": (12 * n + 32 * n, "R pos 8 + radius 4, W 4 cell ids + 4 object ids"),
         "Particle integration pass": (36 * n, "R pos 8 + prev 8 + radius 4, W pos 8 + prev 8"),
         "Collision cell count objects per chunk": (16 * n + 4 * n, "R 4N keys, W N counts"),
@@ -91,7 +96,7 @@ def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gra
     dt = 1.0 / 60.0
     st.run(dt, warmup, resort_every=RESORT_EVERY, resort_first=True)      # first frame re-sorts
     st.ctx.sync()
-    st.ctx.set_profiling(True)
+    st.ctx.set_profiling(PROFILE_EVERY)     # HIP-event pairs around the kernels of every k-th step
     st.ctx.reset_timings()
     if dist is not None:
         dist.barrier()
@@ -142,7 +147,7 @@ def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gr
     dt = 1.0 / 60.0
     st.run(dt, warmup, resort_every=RESORT_EVERY, resort_first=True)
     eng.sync()
-    eng.ctx.set_profiling(True)
+    eng.ctx.set_profiling(PROFILE_EVERY)
     eng.ctx.reset_timings()
     st.stats = {"migrants": 0, "ghosts": 0, "steps": 0}
     dist.barrier()
@@ -259,7 +264,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(dom[1]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": dom[1]["bytes"], "avg_launch_ms": round(dom[1]["avg_ms"], 5),
-                    "launches": dom[1]["calls"]}
+                    "launches": dom[1]["calls"], "launches_are": "the launches of every %dth timed step" % PROFILE_EVERY}
 
     # Whole-job value: every GPU advances one shard of `particles_per_gpu` particles per step, so the job
     # completes n_gpus shard-steps per step (== plain steps/s at n_gpus = 1).

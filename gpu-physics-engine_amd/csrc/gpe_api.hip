@@ -282,7 +282,7 @@ static gpe_status do_solve_colors(gpe_ctx *c)
     return GPE_OK;
 }
 
-static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
+static gpe_status do_step_scoped(gpe_ctx *c, float dt, uint32_t flags)
 {
     // state.rs:115-131
     if (flags & GPE_STEP_RESORT) GPE_TRY(do_resort(c));                          // :122-125
@@ -293,10 +293,11 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
                     "box, bounded density");
     if (native) {
         // grid update + collision solve as N-key sort + LDS cell windows (k_native.hip); the resolved
-        // positions land in the scratch set, which then becomes the live one
-        GPE_TRY(native_collide(c, c->pos, c->pos_copy));
+        // positions land in the scratch set, which then becomes the live one.  The integration (:130) is
+        // applied as the tiles write their particles back -- same arithmetic, one pass over memory less.
+        const VerletParams vp = verlet_params(c, dt);
+        GPE_TRY(native_collide(c, c->pos, c->pos_copy, &vp));
         std::swap(c->pos, c->pos_copy);
-        GPE_TRY(launch_verlet(c, c->pos, c->prev, c->radius, c->n_owned, dt));   // :130
         return GPE_OK;
     }
     GPE_TRY(launch_build_cell_ids(c, c->pos, c->radius, c->n, c->cell_size, c->cell_ids,
@@ -306,6 +307,16 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
     GPE_TRY(do_solve_colors(c));
     GPE_TRY(launch_verlet(c, c->pos, c->prev, c->radius, c->n_owned, dt));       // :130
     return GPE_OK;
+}
+
+// Sampled profiling (gpe_set_profiling(ctx, k > 1)): only every k-th step records its scopes -- an event pair
+// per kernel costs more than some of the kernels at small particle counts.
+static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
+{
+    if (c->profile_every > 1) c->profiling = (c->profile_step++ % c->profile_every) == 0;
+    const gpe_status st = do_step_scoped(c, dt, flags);
+    if (c->profile_every > 1) c->profiling = true;
+    return st;
 }
 
 }  // namespace gpe
@@ -375,6 +386,7 @@ gpe_status gpe_create(const gpe_config *cfg, gpe_ctx **out)
     c->cfg = local;
     c->device = dev;
     c->profiling = local.profiling != 0;
+    c->profile_every = local.profiling;
     if (const char *e = getenv("GPE_SORT")) c->use_onesweep = strcmp(e, "safe") != 0;
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -850,6 +862,8 @@ gpe_status gpe_set_profiling(gpe_ctx *c, uint32_t on)
 {
     if (!c) return GPE_ERR_INVALID_ARG;
     c->profiling = on != 0;
+    c->profile_every = on;
+    c->profile_step = 0;
     return GPE_OK;
 }
 

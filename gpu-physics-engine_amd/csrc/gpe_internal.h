@@ -135,20 +135,44 @@ __device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t
 // case for the high digits of nearly sorted keys), else one atomic per lane.
 __device__ __forceinline__ void hist_add(uint32_t *s_hist, uint32_t d, bool valid)
 {
-    // Peel up to three distinct digit values off the wave (one atomic each: the high digits of
-    // nearly sorted keys hold 1-3 values per wave and per-lane atomics on one word serialise),
-    // then fall back to one atomic per remaining lane (random low digits: few conflicts).
-    uint64_t rem = __ballot(valid);
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        if (rem == 0) return;                                  // wave-uniform
-        const int first = __builtin_ctzll(rem);
-        const uint32_t d0 = __shfl(d, first, 64);
-        const uint64_t same = __ballot(valid && d == d0) & rem;
-        if (lane_id() == first) atomicAdd(&s_hist[d0], (uint32_t)__popcll(same));
-        rem &= ~same;
+    // Only scalar work on the critical path (ballots, one v_readlane): either the whole wave holds one
+    // digit value -- one atomic -- or every lane issues its own fire-and-forget LDS atomic (the LDS
+    // serialises lanes that hit the same bin, which costs less than finding them with cross-lane round trips).
+    const uint64_t m = __ballot(valid);
+    if (m == 0) return;                                        // wave-uniform
+    const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+    if (__ballot(valid && d != d0) == 0) {
+        if (lane_id() == first) atomicAdd(&s_hist[d0], (uint32_t)__popcll(m));
+        return;
     }
-    if ((rem >> lane_id()) & 1ull) atomicAdd(&s_hist[d], 1u);
+    if (valid) atomicAdd(&s_hist[d], 1u);
+}
+
+struct VerletParams {
+    float dt_squared;
+    float world_w, world_h;
+    float acc_x, acc_y;          // FORCE_OF_GRAVITY (particle_integration.wgsl:21)
+    uint32_t mouse_pressed;
+    float mouse_x, mouse_y, mouse_strength;
+};
+
+// particle_integration.wgsl:34-76 for one particle
+__device__ __forceinline__ void verlet_one(float cx, float cy, float qx, float qy, float r,
+                                           const VerletParams &P, float &nx, float &ny)
+{
+    float vx = cx - qx, vy = cy - qy;                       // :40
+    float ax = P.acc_x, ay = P.acc_y;                       // :42
+    if (P.mouse_pressed == 1u) {                            // :44
+        float dx = P.mouse_x - cx, dy = P.mouse_y - cy;     // :46
+        float len = sqrtf(dx * dx + dy * dy);               // :50 normalize()
+        ax = ax + (dx / len) * P.mouse_strength;            // :50,53
+        ay = ay + (dy / len) * P.mouse_strength;
+    }
+    nx = (cx + vx) + ax * P.dt_squared;                     // :59
+    ny = (cy + vy) + ay * P.dt_squared;
+    nx = clamp_f(nx, r, P.world_w - r);                     // :70
+    ny = clamp_f(ny, r, P.world_h - r);                     // :71
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -199,8 +223,6 @@ struct NativeState {
     uint64_t cap = 0;
     uint32_t *tile_ctl = nullptr;    // device control words (k_native.hip kCtl*)
     uint32_t *overflow1 = nullptr;   // packed (ty << 16 | tx) of 32x32 tiles over capacity
-    uint32_t *overflow2 = nullptr;   // ... of 16x16 tiles over capacity (4x as many slots)
-    uint32_t *overflow3 = nullptr;   // ... of 8x8 tiles over the LDS capacity (16x as many slots)
     uint64_t overflow_cap = 0;
     void *arena = nullptr;           // global spill arena for those tiles' particle arrays (37 B per slot)
     uint64_t arena_cap = 0;          // slots
@@ -253,7 +275,9 @@ struct gpe_ctx {
     bool use_onesweep = true;        // GPE_SORT=safe selects the reduce-then-scan sort
 
     // profiling
-    bool profiling = false;
+    bool profiling = false;          // scopes record events now
+    uint32_t profile_every = 0;      // 0 off, 1 every call, k > 1: every k-th step (gpe_set_profiling)
+    uint64_t profile_step = 0;
     std::vector<gpe::ScopeStat> stats;
     std::vector<gpe::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
@@ -312,12 +336,14 @@ gpe_status inclusive_scan(gpe_ctx *c, uint32_t *data, uint64_t n);
 void sort_release(gpe_ctx *c);
 void scan_release(gpe_ctx *c);
 // onesweep (k_onesweep.hip)
+constexpr int kHistCopies = 8;   // digit-histogram copies the hash kernel's workgroups flush into (same-line atomics serialise)
+VerletParams verlet_params(const gpe_ctx *c, float dt);
 gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n);
 void onesweep_release(gpe_ctx *c);
 gpe_status onesweep_zero_hist(gpe_ctx *c);
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
-                         uint32_t **out_vals);
+                         uint32_t **out_vals, bool bases_ready = false);
 // native pipeline (k_native.hip)
 gpe_status native_configure(gpe_ctx *c);
 bool native_should_run(gpe_ctx *c);
@@ -325,7 +351,9 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
                                  int32_t blocks_x, int32_t blocks_y, uint32_t my_rank, uint32_t *out_index,
                                  uint32_t *out_info, uint32_t *out_count, uint64_t out_capacity);
 void native_release(gpe_ctx *c);
-gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out);
+// verlet != nullptr: K12 is applied to the first n_owned particles as they are written back (pos_out = integrated
+// position, prev = resolved position) -- the separate integration launch is then skipped
+gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, const VerletParams *verlet = nullptr);
 // collision cells + solver
 gpe_status launch_count_chunks(gpe_ctx *c, const uint32_t *cell_ids, uint64_t total, uint32_t *chunk_counts);
 gpe_status launch_build_collision_cells(gpe_ctx *c, const uint32_t *cell_ids, uint64_t total,

@@ -22,6 +22,7 @@
 // read a tile's step-start positions while it writes its results.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -64,57 +65,119 @@ constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS ca
 constexpr uint32_t kErrRegion = 4u;            // internal: particle outside its staged region
 // tile_ctl words (the first four are cleared every step, the error word is sticky)
 constexpr int kCtlOverflow1 = 0;               // 32x32 tiles over capacity this step
-constexpr int kCtlOverflow2 = 1;               // 16x16 tiles over capacity this step
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
 constexpr int kCtlArena = 3;                   // particles handed out of the global spill arena this step
-constexpr int kCtlOverflow3 = 4;               // 8x8 tiles over the LDS capacity this step (-> global arena)
+constexpr int kCtlHashDone = 4;                // hash workgroups that have flushed their histograms
 constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every step
 constexpr int kCtlError = 8;                   // sticky
 constexpr uint64_t kArenaBytesPerSlot = 37;    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
-constexpr int kTileMain = 32, kCapMain = 960;
+constexpr int kTileMain = 32, kCapMain = 1120;
 constexpr int kTileMid = 16, kCapMid = 1920;
 constexpr int kTileSmall = 8, kCapSmall = 2048;
 constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows above this population
 
 // ---------------------------------------------------------------------------------------------------
+// clear: one launch zeroes everything a step accumulates into (block table, digit histograms, per-step
+// control words) and hands the previous step's window statistic to the host (pinned memory).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStreamBlock) void k_native_clear(uint4 *__restrict__ table2, uint64_t table_pairs,
+                                                               uint32_t *__restrict__ hist4,
+                                                               uint32_t *__restrict__ tile_ctl,
+                                                               uint32_t *__restrict__ host_stat)
+{
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kStreamBlock) hist4[i] = 0;
+        if (threadIdx.x == 0 && host_stat) host_stat[0] = tile_ctl[kCtlWindowMax];
+        __syncthreads();
+        if (threadIdx.x < kCtlPerStepWords) tile_ctl[threadIdx.x] = 0;
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += stride)
+        table2[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
 // (home_cell_ids.wgsl:24-31 computes the same key; the particle id is implicit in the first pass.)
+// The workgroup that flushes its histogram last also turns the histograms into the digit bases of the four
+// passes and resets the tile tickets (k_os_prepare's job): one launch less on the step path.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kStreamBlock) void k_native_hash(const float2 *__restrict__ pos, uint64_t n,
-                                                              float cell_size, int32_t gx, int32_t gy,
-                                                              uint32_t *__restrict__ keys,
-                                                              uint32_t *__restrict__ hist4,
-                                                              uint32_t *__restrict__ tile_ctl)
+// Every workgroup flushes up to 256 bins per digit with device-scope atomics (they resolve beyond the per-XCD
+// L2s): FEW, LARGE workgroups (1024 lanes, at most one per CU) keep the flush small however many particles
+// there are.
+constexpr int kHashBlock = 1024;
+constexpr int kHashBatch = 8;                  // positions loaded per lane before any of them is ranked
+__global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__restrict__ pos, uint64_t n,
+                                                            float cell_size, int32_t gx, int32_t gy,
+                                                            uint32_t *__restrict__ keys, int digits,
+                                                            uint32_t *hist4, uint32_t *__restrict__ bases4,
+                                                            uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl)
 {
     __shared__ uint32_t s_hist[4 * 256];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) s_hist[p * 256 + threadIdx.x] = 0;
+    __shared__ uint32_t s_w[kHashBlock / 64];
+    __shared__ uint32_t s_last;
+    s_hist[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (n + stride - 1) / stride;
     bool oob = false;
-    for (uint64_t r = 0; r < rounds; ++r) {
-        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool valid = i < n;
-        uint32_t key = 0;
-        if (valid) {
-            const float2 p = pos[i];
-            const int32_t cx = cell_coord(p.x, cell_size), cy = cell_coord(p.y, cell_size);
-            oob |= (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy);
-            key = morton_encode(cx, cy);
-            keys[i] = key;
+    for (uint64_t r0 = 0; r0 < rounds; r0 += kHashBatch) {
+        float2 p[kHashBatch];
+        uint64_t idx[kHashBatch];
+#pragma unroll
+        for (int u = 0; u < kHashBatch; ++u) {                        // the loads of a batch are in flight together
+            idx[u] = (r0 + u) * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            p[u] = (r0 + u < rounds && idx[u] < n) ? pos[idx[u]] : make_float2(0.f, 0.f);
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) hist_add(s_hist + p * 256, (key >> (8 * p)) & 255u, valid);
+        for (int u = 0; u < kHashBatch; ++u) {
+            if (r0 + u >= rounds) break;                               // wave-uniform
+            const bool valid = idx[u] < n;
+            uint32_t key = 0;
+            if (valid) {
+                const int32_t cx = cell_coord(p[u].x, cell_size), cy = cell_coord(p[u].y, cell_size);
+                oob |= (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy);
+                key = morton_encode(cx, cy);
+                keys[idx[u]] = key;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < digits) hist_add(s_hist + q * 256, (key >> (8 * q)) & 255u, valid);
+        }
     }
     if (oob) atomicOr(&tile_ctl[kCtlError], kErrOutOfBox);
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const uint32_t v = s_hist[p * 256 + threadIdx.x];
-        if (v) atomicAdd(&hist4[p * 256 + threadIdx.x], v);
+    // Flush with RETURNING device-scope atomics and wait for the returns: when the barrier below opens, every
+    // add of this workgroup has been performed, so the ticket can follow without a release fence (an
+    // agent-scope fence here writes the L2 back -- the keys just stored -- once per workgroup: 3x the kernel).
+    if ((threadIdx.x & 1u) == 0) {
+        // two neighbouring bins per 64-bit atomic (no bin reaches 2^32, so nothing carries into the upper one)
+        const uint32_t lo = s_hist[threadIdx.x], hi = s_hist[threadIdx.x + 1];   // index = digit * 256 + bin
+        if (lo | hi) {
+            const unsigned long long old = __hip_atomic_fetch_add(
+                reinterpret_cast<unsigned long long *>(&hist4[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
+                (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"((uint32_t)old));                     // the return value must have arrived
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&tile_ctl[kCtlHashDone], 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0) return;
+    // k_os_prepare's job: exclusive digit bases per pass (four waves scan one digit), tile tickets reset
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < kHistCopies; ++k)
+        v += __hip_atomic_load(&hist4[k * 1024 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t inc = wave_inclusive_scan(v);
+    const int w = (int)(threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = w & ~3; i < w; ++i) base += s_w[i];
+    bases4[threadIdx.x] = base + inc - v;
+    if (threadIdx.x < 8) os_ctl[threadIdx.x] = 0;                      // tile tickets + error word
 }
 
 // Largest particle count of any 3x3-block (24x24-cell) window: what the smallest cell window must hold.
@@ -195,15 +258,16 @@ struct CollideArgs {
     uint32_t *tile_ctl;          // kCtl* words
     uint32_t *overflow1;         // packed (ty << 16 | tx) of over-capacity 32x32 tiles
     uint32_t overflow1_cap;
-    uint32_t *overflow2;         // ... of over-capacity 16x16 tiles
-    uint32_t overflow2_cap;
-    uint32_t *overflow3;         // ... of 8x8 tiles over the LDS capacity: staged in the global arena instead
-    uint32_t overflow3_cap;
     // spill arena (global memory) for the particle arrays of such tiles
     float *arena_px, *arena_py, *arena_rad;
     uint32_t *arena_id, *arena_hm, *arena_mem;   // arena_mem holds 4 entries per particle
     uint8_t *arena_sblk;
     uint32_t arena_cap;
+    // K12 fused into the write-back (particle_integration.wgsl:25-77) when fuse_verlet != 0
+    float2 *prev;
+    uint64_t n_owned;
+    uint32_t fuse_verlet;
+    VerletParams vp;
     unsigned long long *stamps;  // diagnostic builds only (-DGPE_TILE_STAMPS): cycles per phase, thread 0
 };
 
@@ -239,8 +303,25 @@ struct TileLds {
     uint32_t hm[CAP];          // bits 0-15 local index of the home cell; bits 16-27 phantom-cell codes
                                // (3 x 4 bit, (dy+1)*3+(dx+1)); bits 28-29 number of phantom cells
     // cell[lc + 1]: members of cell lc (P1) -> first slot of its list (P2) -> one past its last slot (P3);
-    // cell[0] = 0, so from P3 on the list of cell lc is mem[cell[lc] .. cell[lc + 1])
-    uint32_t cell[NCELL + 1];
+    // cell[0] = 0, so from P3 on the list of cell lc is mem[cell[lc] .. cell[lc + 1]).  Values stay below
+    // 4 * CAP < 65536: two cells share a word (LDS atomics are 32 bit, so cell_inc adds 1 or 1 << 16 --
+    // no carry can leave the low half), which buys 160 more particles per window than 32-bit cells.
+    static_assert(4 * CAP < 65536, "cell offsets are 16 bit");
+    union {
+        uint32_t cellw[(NCELL + 2) / 2];
+        uint16_t cellh[NCELL + 2];
+    };
+    __device__ __forceinline__ void cell_clear(int tid)
+    {
+        for (int i = tid; i < (NCELL + 2) / 2; i += kNatThreads) cellw[i] = 0;
+    }
+    __device__ __forceinline__ uint32_t cell_get(int i) const { return cellh[i]; }
+    __device__ __forceinline__ void cell_set(int i, uint32_t v) { cellh[i] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t cell_inc(int i)                // returns the value before the add
+    {
+        const uint32_t sh = (uint32_t)(i & 1) * 16u;
+        return (atomicAdd(&cellw[i >> 1], 1u << sh) >> sh) & 0xFFFFu;
+    }
     union {
         uint16_t mem[4 * CAP]; // member lists (local particle slots)
         uint8_t sblk[CAP];     // P0-P1 only: region block a staged slot came from
@@ -271,7 +352,14 @@ struct TileGlobal {
     float *px, *py, *rad;
     uint32_t *id, *hm, *mem;
     uint8_t *sblk;
-    uint32_t cell[NCELL + 1];
+    uint32_t cell[NCELL + 1];      // 32-bit cells: the member count is not bounded by an LDS capacity here
+    __device__ __forceinline__ void cell_clear(int tid)
+    {
+        for (int i = tid; i <= NCELL; i += kNatThreads) cell[i] = 0;
+    }
+    __device__ __forceinline__ uint32_t cell_get(int i) const { return cell[i]; }
+    __device__ __forceinline__ void cell_set(int i, uint32_t v) { cell[i] = v; }
+    __device__ __forceinline__ uint32_t cell_inc(int i) { return atomicAdd(&cell[i], 1u); }
     uint16_t list[4 * QZ];
     uint32_t lcnt[4];
     uint32_t bstart[NBLK];
@@ -372,7 +460,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
     GPE_STAMP_BEGIN();
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
-    for (int i = tid; i <= NCELL; i += kNatThreads) S.cell[i] = 0;
+    S.cell_clear(tid);
     if (tid < 4) S.lcnt[tid] = 0;
     if (tid < NBLK) {
         const int bi = tid % NB, bj = tid / NB;
@@ -497,7 +585,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
             }
             S.px[s] = p.x; S.py[s] = p.y; S.rad[s] = r; S.id[s] = pid[q];
             const int home = ly * RW + lx;
-            atomicAdd(&S.cell[home + 1], 1u);
+            S.cell_inc(home + 1);
             // phantom cells in the reference's scan order (grid.wgsl:68-90), at most three kept.
             // is_obj_in_cell (grid.wgsl:117-129) per axis: the clamped offset of neighbour column i /
             // row j does not depend on the other axis, so the 8 tests share 3 + 3 squared offsets
@@ -523,7 +611,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
                             code |= (uint32_t)((y + 1) * 3 + (x + 1)) << (4 * pc);
                             const int nlx = lx + x, nly = ly + y;
                             if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW)
-                                atomicAdd(&S.cell[nly * RW + nlx + 1], 1u);
+                                S.cell_inc(nly * RW + nlx + 1);
                         }
                         ++pc;
                     }
@@ -541,11 +629,11 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
         uint32_t cn[PER];
         uint32_t sum = 0;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { cn[k] = (c0 + k < NCELL) ? S.cell[c0 + k + 1] : 0u; sum += cn[k]; }
+        for (int k = 0; k < PER; ++k) { cn[k] = (c0 + k < NCELL) ? S.cell_get(c0 + k + 1) : 0u; sum += cn[k]; }
         uint32_t run = nat_block_exclusive_scan(sum, S.s_w, nullptr);
 #pragma unroll
         for (int k = 0; k < PER; ++k)
-            if (c0 + k < NCELL) { S.cell[c0 + k + 1] = run; run += cn[k]; }
+            if (c0 + k < NCELL) { S.cell_set(c0 + k + 1, run); run += cn[k]; }
     }
     __syncthreads();
     GPE_STAMP(2);
@@ -554,7 +642,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
     for (uint32_t s = tid; s < P; s += kNatThreads) {
         const uint32_t hm = S.hm[s];
         const int home = (int)(hm & 0xFFFFu);
-        uint32_t k = atomicAdd(&S.cell[home + 1], 1u);
+        uint32_t k = S.cell_inc(home + 1);
         S.mem[k] = s;
         const uint32_t pc = hm >> 28;
         const int lx = home % RW, ly = home / RW;
@@ -563,7 +651,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
             const int nlx = lx + (nb % 3) - 1, nly = ly + (nb / 3) - 1;
             if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) {
                 const int lc = nly * RW + nlx;
-                k = atomicAdd(&S.cell[lc + 1], 1u);
+                k = S.cell_inc(lc + 1);
                 S.mem[k] = s;
             }
         }
@@ -586,7 +674,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
                 if (i < QC) {
                     const int lx = 2 * (i % HW) + px0, ly = 2 * (i / HW) + py0;
                     lc = ly * RW + lx;
-                    const uint32_t b = S.cell[lc], e = S.cell[lc + 1];
+                    const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
                     const int gxx = ox + lx, gyy = oy + ly;
                     const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
                     const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
@@ -619,7 +707,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
         const uint32_t nk = S.lcnt[k];
         for (uint32_t i = tid; i < nk; i += kNatThreads) {
             const int lc = S.list[k * L::QZ + i];
-            const uint32_t b = S.cell[lc], e = S.cell[lc + 1];
+            const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
             sort_members(S, b, e);
             resolve_cell(S, b, e, A.stiffness);
         }
@@ -647,7 +735,18 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
                 }
                 id = A.sorted_ids[S.bstart[lo] + (s - S.boff[lo])];
             }
-            A.pos_out[id] = make_float2(S.px[s], S.py[s]);
+            const float2 c = make_float2(S.px[s], S.py[s]);
+            if (A.fuse_verlet && id < A.n_owned) {
+                // K12 on the resolved position: the integrated position becomes the live one, the resolved
+                // position the previous one (particle_integration.wgsl:64,76)
+                const float2 q = A.prev[id];
+                float2 o;
+                verlet_one(c.x, c.y, q.x, q.y, S.rad[s], A.vp, o.x, o.y);
+                A.prev[id] = c;
+                A.pos_out[id] = o;
+            } else {
+                A.pos_out[id] = c;
+            }
         }
     }
     __syncthreads();
@@ -676,46 +775,46 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     }
 }
 
-// Levels 1-3: the over-capacity tiles of the previous level are redone by a fixed grid that strides over the
-// device-side list (HIP has no indirect dispatch).  LEVEL 1: 32x32 parents as four 16x16 tiles; LEVEL 2: 16x16
-// parents as four 8x8 tiles; LEVEL 3: 8x8 tiles again, with their particle arrays in the global spill arena.
-template <class L, int LEVEL>
-__global__ __launch_bounds__(kNatThreads) void k_collide_sublist(CollideArgs A)
+// Over-capacity 32x32 tiles are redone by a fixed grid that strides over the device-side list (HIP has no
+// indirect dispatch): one work item per 16x16 quarter.  A quarter whose 32x32-cell region is still over capacity
+// is redone by the same workgroup as four 8x8 tiles, and an 8x8 tile whose 24x24-cell window exceeds even that
+// LDS capacity gets its particle arrays from the global spill arena.  One launch, no queue, nothing to wait for.
+__global__ __launch_bounds__(kNatThreads) void k_collide_overflow(CollideArgs A)
 {
-    __shared__ L S;
-    constexpr uint32_t SPLIT = (LEVEL == 3) ? 1u : 2u;
-    const uint32_t *list = (LEVEL == 1) ? A.overflow1 : (LEVEL == 2) ? A.overflow2 : A.overflow3;
-    const uint32_t cap = (LEVEL == 1) ? A.overflow1_cap : (LEVEL == 2) ? A.overflow2_cap : A.overflow3_cap;
-    uint32_t count = A.tile_ctl[(LEVEL == 1) ? kCtlOverflow1 : (LEVEL == 2) ? kCtlOverflow2 : kCtlOverflow3];
-    if (count > cap) count = cap;
-    const uint32_t work = count * SPLIT * SPLIT;
+    using Mid = TileLds<kTileMid, kCapMid>;
+    using Small = TileLds<kTileSmall, kCapSmall>;
+    using Spill = TileGlobal<kTileSmall>;
+    __shared__ union U { Mid mid; Small small; Spill spill; } u;
+    uint32_t count = A.tile_ctl[kCtlOverflow1];
+    if (count > A.overflow1_cap) count = A.overflow1_cap;
+    const uint32_t work = count * 4u;
     for (uint32_t i = blockIdx.x; i < work; i += gridDim.x) {
-        const uint32_t parent = list[i / (SPLIT * SPLIT)];
-        const uint32_t sub = i % (SPLIT * SPLIT);
-        const int tx = (int)((parent & 0xFFFFu) * SPLIT + sub % SPLIT), ty = (int)((parent >> 16) * SPLIT + sub / SPLIT);
-        if (process_tile(S, A, tx, ty)) continue;
-        if (LEVEL < 3) {
-            uint32_t *out = (LEVEL == 1) ? A.overflow2 : A.overflow3;
-            const uint32_t out_cap = (LEVEL == 1) ? A.overflow2_cap : A.overflow3_cap;
-            if (threadIdx.x == 0) {
-                const uint32_t slot = atomicAdd(&A.tile_ctl[(LEVEL == 1) ? kCtlOverflow2 : kCtlOverflow3], 1u);
-                if (slot < out_cap) out[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
-                else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
-            }
-        } else {
+        const uint32_t parent = A.overflow1[i >> 2];
+        const int tx = (int)((parent & 0xFFFFu) * 2u + (i & 1u)), ty = (int)((parent >> 16) * 2u + ((i >> 1) & 1u));
+        const bool done = process_tile(u.mid, A, tx, ty);
+        __syncthreads();                                               // the union's views alias each other
+        if (done) continue;
+        for (int sub = 0; sub < 4; ++sub) {
+            const int sx = tx * 2 + (sub & 1), sy = ty * 2 + (sub >> 1);
+            bool ok = process_tile(u.small, A, sx, sy);
+            __syncthreads();
+            if (ok) continue;
+            ok = process_tile(u.spill, A, sx, sy);
+            __syncthreads();
+            if (ok) continue;
             // the spill arena is exhausted: flag it (gpe_sync / gpe_download report the error) and pass the
             // tile's own particles through unresolved so that the state stays finite
             if (threadIdx.x == 0) atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
-            for (int b = threadIdx.x; b < L::NBLK; b += kNatThreads) {
-                const int bi = b % L::NB, bj = b / L::NB;
-                if (bi < 1 || bi >= L::NB - 1 || bj < 1 || bj >= L::NB - 1) continue;
-                for (uint32_t q = 0; q < S.bcnt[b]; ++q) {
-                    const uint32_t id = A.sorted_ids[S.bstart[b] + q];
+            for (int b = threadIdx.x; b < Spill::NBLK; b += kNatThreads) {
+                const int bi = b % Spill::NB, bj = b / Spill::NB;
+                if (bi < 1 || bi >= Spill::NB - 1 || bj < 1 || bj >= Spill::NB - 1) continue;
+                for (uint32_t q = 0; q < u.spill.bcnt[b]; ++q) {
+                    const uint32_t id = A.sorted_ids[u.spill.bstart[b] + q];
                     A.pos_out[id] = A.pos_in[id];
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -742,8 +841,6 @@ void native_release(gpe_ctx *c)
     if (N.ids_b) (void)hipFree(N.ids_b);
     if (N.tile_ctl) (void)hipFree(N.tile_ctl);
     if (N.overflow1) (void)hipFree(N.overflow1);
-    if (N.overflow2) (void)hipFree(N.overflow2);
-    if (N.overflow3) (void)hipFree(N.overflow3);
     if (N.arena) (void)hipFree(N.arena);
     if (N.host_stat) (void)hipHostFree(N.host_stat);
     N = NativeState();
@@ -754,22 +851,26 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
 {
     NativeState &N = c->native;
     const uint64_t n = c->n;
-    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, kCtlPerStepWords * 4, c->stream));   // the error word stays
-    GPE_HIP(c, hipMemsetAsync(N.block_table, 0, (size_t)N.table_entries * sizeof(uint2), c->stream));
-    GPE_TRY(onesweep_zero_hist(c));
+    {
+        Scope s(c, "native/clear");
+        const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;    // the table is allocated in 16-byte units
+        hipLaunchKernelGGL(k_native_clear, dim3(stream_grid(pairs)), dim3(kStreamBlock), 0, c->stream,
+                           (uint4 *)N.block_table, pairs, c->os_ws.hist4, N.tile_ctl, N.host_stat);
+        GPE_HIP(c, hipGetLastError());
+    }
     {
         Scope s(c, "native/hash");
-        // every workgroup flushes up to 1024 histogram bins with global atomics: at least 16 keys per lane
-        // per workgroup keeps that flush small next to the streaming work
-        const int grid = std::min(stream_grid(n), std::max(1, (int)(n / (16 * kStreamBlock))));
-        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kStreamBlock), 0, c->stream, c->pos, n,
-                           c->cell_size, N.gx, N.gy, N.keys, c->os_ws.hist4, N.tile_ctl);
+        // one workgroup per CU at most, at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
+        const int grid = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
+        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, n,
+                           c->cell_size, N.gx, N.gy, N.keys, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl,
+                           N.tile_ctl);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
     {
         Scope s(c, "native/sort");
-        GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv));
+        GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv, true));
     }
     {
         Scope s(c, "native/table");
@@ -807,7 +908,7 @@ gpe_status native_configure(gpe_ctx *c)
     if (N.table_cap < N.table_entries) {
         if (N.block_table) GPE_HIP(c, hipFree(N.block_table));
         N.block_table = nullptr; N.table_cap = 0;
-        GPE_HIP(c, hipMalloc((void **)&N.block_table, (size_t)N.table_entries * sizeof(uint2)));
+        GPE_HIP(c, hipMalloc((void **)&N.block_table, ((size_t)N.table_entries + 2) * sizeof(uint2)));
         N.table_cap = N.table_entries;
     }
     if (N.cap < c->cap) {
@@ -822,12 +923,8 @@ gpe_status native_configure(gpe_ctx *c)
     const uint64_t tiles = (uint64_t)((N.gx + kTileMain - 1) / kTileMain) * ((N.gy + kTileMain - 1) / kTileMain);
     if (N.overflow_cap < tiles) {
         if (N.overflow1) GPE_HIP(c, hipFree(N.overflow1));
-        if (N.overflow2) GPE_HIP(c, hipFree(N.overflow2));
-        if (N.overflow3) GPE_HIP(c, hipFree(N.overflow3));
-        N.overflow1 = N.overflow2 = N.overflow3 = nullptr; N.overflow_cap = 0;
+        N.overflow1 = nullptr; N.overflow_cap = 0;
         GPE_HIP(c, hipMalloc((void **)&N.overflow1, (tiles + 16) * sizeof(uint32_t)));
-        GPE_HIP(c, hipMalloc((void **)&N.overflow2, (4 * tiles + 16) * sizeof(uint32_t)));
-        GPE_HIP(c, hipMalloc((void **)&N.overflow3, (16 * tiles + 16) * sizeof(uint32_t)));
         N.overflow_cap = tiles;
     }
     {
@@ -903,7 +1000,7 @@ bool native_should_run(gpe_ctx *c)
 }
 
 // pos_in (step-start positions) -> pos_out (after the four colour passes), every particle written.
-gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
+gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, const VerletParams *verlet)
 {
     NativeState &N = c->native;
     uint32_t *sorted_ids = nullptr;
@@ -922,10 +1019,6 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     A.tile_ctl = N.tile_ctl;
     A.overflow1 = N.overflow1;
     A.overflow1_cap = (uint32_t)N.overflow_cap;
-    A.overflow2 = N.overflow2;
-    A.overflow2_cap = (uint32_t)(4 * N.overflow_cap);
-    A.overflow3 = N.overflow3;
-    A.overflow3_cap = (uint32_t)(16 * N.overflow_cap);
     {
         // arena layout: px | py | rad | id | hm | mem (4 per slot) | sblk
         float *f = (float *)N.arena;
@@ -938,6 +1031,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     }
     A.order_keys = c->use_order_keys ? c->order_keys : nullptr;
     A.tile_x0 = A.tile_y0 = 0;
+    A.prev = c->prev;
+    A.n_owned = c->n_owned;
+    A.fuse_verlet = verlet ? 1u : 0u;
+    if (verlet) A.vp = *verlet; else memset(&A.vp, 0, sizeof(A.vp));
     A.stamps = nullptr;
 #ifdef GPE_TILE_STAMPS
     static unsigned long long *g_stamps = nullptr;
@@ -955,7 +1052,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
     }
 #endif
     {
-        Scope s(c, "native/collide");
+        Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
         int32_t cx0 = 0, cy0 = 0, cx1 = N.gx - 1, cy1 = N.gy - 1;
         if (c->has_active_box) {                                       // sharded: only this rank's cells
             cx0 = std::max(cx0, c->active_box[0]); cy0 = std::max(cy0, c->active_box[1]);
@@ -972,21 +1069,11 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out)
         GPE_HIP(c, hipGetLastError());
     }
     {
-        // tiles whose 48x48-cell region exceeded the LDS capacity: 16x16 tiles, then 8x8 tiles
+        // tiles whose 48x48-cell region exceeded the LDS capacity: 16x16 tiles, 8x8 tiles, spill arena
         Scope s(c, "native/collide-dense-regions");
-        hipLaunchKernelGGL((k_collide_sublist<TileLds<kTileMid, kCapMid>, 1>), dim3(512), dim3(kNatThreads), 0,
-                           c->stream, A);
-        GPE_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL((k_collide_sublist<TileLds<kTileSmall, kCapSmall>, 2>), dim3(512), dim3(kNatThreads), 0,
-                           c->stream, A);
-        GPE_HIP(c, hipGetLastError());
-        // 8x8 tiles whose 24x24-cell window exceeds the LDS capacity: particle arrays in the global arena
-        hipLaunchKernelGGL((k_collide_sublist<TileGlobal<kTileSmall>, 3>), dim3(256), dim3(kNatThreads), 0,
-                           c->stream, A);
+        hipLaunchKernelGGL(k_collide_overflow, dim3(512), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
-    GPE_HIP(c, hipMemcpyAsync(N.host_stat, N.tile_ctl + kCtlWindowMax, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              c->stream));
     return GPE_OK;
 }
 

@@ -17,6 +17,9 @@
 // words carry an epoch (sort call x pass), so the array is never cleared between passes; spins are
 // bounded and report through an error word instead of hanging the GPU.
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "gpe_internal.h"
 
@@ -35,17 +38,17 @@
 
 namespace gpe {
 
-#ifndef GPE_OS_WIN
-#define GPE_OS_WIN 8
-#endif
 #ifndef GPE_OS_MINWAVES
 #define GPE_OS_MINWAVES 4
 #endif
 constexpr int kOsBlock = 512;
 constexpr int kOsWaves = kOsBlock / 64;
+// 8192-key tiles, look-back window of 8: measured best from 1 M to 100 M keys (2048-key tiles and a 32-word
+// window were each 10-50% slower per pass at 1 M, 4 M and 16 M keys -- profiles/r01/tune_onesweep.txt)
 constexpr int kOsItems = 16;
-constexpr int kOsTile = kOsBlock * kOsItems;     // 8192 keys
+constexpr int kOsTile = kOsBlock * kOsItems;
 constexpr int kOsWaveSpan = 64 * kOsItems;
+constexpr int kWin = 8;
 
 constexpr uint64_t kFlagAggregate = 1ull;        // value = this tile's count of the digit
 constexpr uint64_t kFlagPrefix = 2ull;           // value = count of the digit in tiles 0..this
@@ -57,7 +60,8 @@ __device__ __forceinline__ uint64_t os_match_digit(uint32_t d, bool valid)
 {
     uint64_t m = __ballot(valid);
     // whole wave on one digit (the usual case for the high digits of nearly sorted keys)
-    const uint32_t d0 = __shfl(d, m ? __builtin_ctzll(m) : 0, 64);
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane(
+        (int)d, __builtin_amdgcn_readfirstlane(m ? (int)__builtin_ctzll(m) : 0));
     if (__ballot(valid && d != d0) == 0) return m;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -110,6 +114,20 @@ __global__ __launch_bounds__(256) void k_os_prepare(const uint32_t *__restrict__
 __device__ __forceinline__ u64 status_pack(uint32_t epoch, uint64_t flag, uint32_t value)
 {
     return ((u64)epoch << 34) | (flag << 32) | (u64)value;
+}
+
+// spin (bounded) until the status word carries this epoch and a flag
+// (returns 0 -- no flag -- when the bound is hit)
+__device__ __noinline__ u64 os_wait_status(const u64 *p, uint32_t epoch)
+{
+    u64 sv;
+    uint32_t spins = 0;
+    do {
+        if (++spins > kSpinLimit) return 0;
+        __builtin_amdgcn_s_sleep(1);
+        sv = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((uint32_t)(sv >> 34) != epoch || ((sv >> 32) & 3ull) == 0ull);
+    return sv;
 }
 
 // exclusive scan of one value per thread over the kOsBlock threads of the pass kernel
@@ -234,7 +252,6 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
         uint32_t before = 0;                                   // digit d in tiles [0, tile)
         bool failed = false;
         uint32_t hops = 0, total_spins = 0;
-        constexpr int kWin = GPE_OS_WIN;
         bool done = (tile == 0);
         for (int64_t t = (int64_t)tile - 1; !done && !failed; t -= kWin) {
             u64 sw[kWin];
@@ -245,19 +262,19 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
                                      : status_pack(epoch, kFlagPrefix, 0u);       // before tile 0: nothing
 #pragma unroll
             for (int i = 0; i < kWin; ++i) {
-                if (done || failed) break;
-                u64 sv = sw[i];
-                uint32_t spins = 0;
-                while ((uint32_t)(sv >> 34) != epoch || ((sv >> 32) & 3ull) == 0ull) {   // not published yet
-                    if (++spins > kSpinLimit) { failed = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    sv = __hip_atomic_load(status + (uint64_t)(t - i) * 256 + d, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                if (!done && !failed) {
+                    u64 sv = sw[i];
+                    if ((uint32_t)(sv >> 34) != epoch || ((sv >> 32) & 3ull) == 0ull) {      // not published yet
+                        sv = os_wait_status(status + (uint64_t)(t - i) * 256 + d, epoch);
+                        failed = (sv == 0);
+                        ++total_spins;
+                    }
+                    if (!failed) {
+                        ++hops;
+                        before += (uint32_t)sv;
+                        if (((sv >> 32) & 3ull) == kFlagPrefix) done = true;
+                    }
                 }
-                if (failed) break;
-                ++hops; total_spins += spins;
-                before += (uint32_t)sv;
-                if (((sv >> 32) & 3ull) == kFlagPrefix) done = true;
             }
         }
 #ifdef GPE_OS_STAMPS
@@ -314,10 +331,13 @@ gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n)
         ws.status_cap = need;
     }
     if (!ws.hist4) {
-        GPE_HIP(c, hipMalloc((void **)&ws.hist4, (4 * 256 + 4 * 256 + 64) * sizeof(uint32_t)));
-        ws.bases4 = ws.hist4 + 4 * 256;
+        // kHistCopies histograms (the fused hash kernel spreads its flush atomics over them; the generic
+        // path uses copy 0), the digit bases, the control words
+        const size_t words = (size_t)kHistCopies * 4 * 256 + 4 * 256 + 64;
+        GPE_HIP(c, hipMalloc((void **)&ws.hist4, words * sizeof(uint32_t)));
+        ws.bases4 = ws.hist4 + (size_t)kHistCopies * 4 * 256;
         ws.ctl = ws.bases4 + 4 * 256;
-        GPE_HIP(c, hipMemsetAsync(ws.hist4, 0, (4 * 256 + 4 * 256 + 64) * sizeof(uint32_t), c->stream));
+        GPE_HIP(c, hipMemsetAsync(ws.hist4, 0, words * sizeof(uint32_t), c->stream));
     }
     return GPE_OK;
 }
@@ -338,11 +358,12 @@ gpe_status onesweep_zero_hist(gpe_ctx *c)
 
 // Passes over digits [0, passes): (keys, vals) ping-pong with (keys_b, vals_b).  Returns through
 // *out_keys/*out_vals the buffers holding the result (the caller's when `passes` is even).
-// hist_ready: hist4 already holds the four digit histograms of `keys` (fused producer).
+// hist_ready: hist4 already holds the four digit histograms of `keys` (fused producer);
+// bases_ready: that producer has also done k_os_prepare's work (digit bases, tickets reset).
 // iota_vals: the payload is the identity permutation and `vals` need not be initialised.
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
-                         uint32_t **out_vals)
+                         uint32_t **out_vals, bool bases_ready)
 {
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
@@ -358,7 +379,7 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
                            ws.hist4);
         GPE_HIP(c, hipGetLastError());
     }
-    {
+    if (!(hist_ready && bases_ready)) {
         Scope s(c, "sort/prepare");
         hipLaunchKernelGGL(k_os_prepare, dim3(1), dim3(256), 0, c->stream, ws.hist4, ws.bases4, ws.ctl);
         GPE_HIP(c, hipGetLastError());
@@ -371,14 +392,10 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
             ws.epoch = 1;
         }
         Scope s(c, "sort/onesweep");
-        if (p == 0 && iota_vals)
-            hipLaunchKernelGGL(k_os_pass<true>, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb,
-                               vb, n, (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl,
-                               ws.epoch);
-        else
-            hipLaunchKernelGGL(k_os_pass<false>, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb,
-                               vb, n, (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl,
-                               ws.epoch);
+        const bool iota = (p == 0 && iota_vals);
+        const auto kern = iota ? k_os_pass<true> : k_os_pass<false>;
+        hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb, vb, n,
+                           (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl, ws.epoch);
         GPE_HIP(c, hipGetLastError());
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;

@@ -39,32 +39,6 @@ __global__ __launch_bounds__(kStreamBlock) void k_rearrange(const float2 *__rest
     }
 }
 
-struct VerletParams {
-    float dt_squared;
-    float world_w, world_h;
-    float acc_x, acc_y;          // FORCE_OF_GRAVITY (particle_integration.wgsl:21)
-    uint32_t mouse_pressed;
-    float mouse_x, mouse_y, mouse_strength;
-};
-
-// particle_integration.wgsl:34-76 for one particle
-__device__ __forceinline__ void verlet_one(float cx, float cy, float qx, float qy, float r,
-                                           const VerletParams &P, float &nx, float &ny)
-{
-    float vx = cx - qx, vy = cy - qy;                       // :40
-    float ax = P.acc_x, ay = P.acc_y;                       // :42
-    if (P.mouse_pressed == 1u) {                            // :44
-        float dx = P.mouse_x - cx, dy = P.mouse_y - cy;     // :46
-        float len = sqrtf(dx * dx + dy * dy);               // :50 normalize()
-        ax = ax + (dx / len) * P.mouse_strength;            // :50,53
-        ay = ay + (dy / len) * P.mouse_strength;
-    }
-    nx = (cx + vx) + ax * P.dt_squared;                     // :59
-    ny = (cy + vy) + ay * P.dt_squared;
-    nx = clamp_f(nx, r, P.world_w - r);                     // :70
-    ny = clamp_f(ny, r, P.world_h - r);                     // :71
-}
-
 // K12 particles/particle_integration.wgsl:25-77.  R 20 B, W 16 B per particle; two particles per
 // lane per iteration so every access is 16 B/lane (pos, prev) or 8 B/lane (radius).
 __global__ __launch_bounds__(kStreamBlock) void k_verlet(float2 *__restrict__ pos,
@@ -120,11 +94,8 @@ gpe_status launch_rearrange(gpe_ctx *c, const float2 *pos, const float2 *prev, c
     return GPE_OK;
 }
 
-gpe_status launch_verlet(gpe_ctx *c, float2 *pos, float2 *prev, const float *radius, uint64_t n,
-                         float dt)
+VerletParams verlet_params(const gpe_ctx *c, float dt)
 {
-    if (n == 0) return GPE_OK;
-    Scope s(c, "Particle integration pass");  // particle_integration.rs:81
     VerletParams P;
     P.dt_squared = dt * dt;                   // particle_integration.wgsl:58
     P.world_w = c->cfg.world_width;
@@ -135,6 +106,15 @@ gpe_status launch_verlet(gpe_ctx *c, float2 *pos, float2 *prev, const float *rad
     P.mouse_x = c->mouse_x;
     P.mouse_y = c->mouse_y;
     P.mouse_strength = c->cfg.mouse_strength;
+    return P;
+}
+
+gpe_status launch_verlet(gpe_ctx *c, float2 *pos, float2 *prev, const float *radius, uint64_t n,
+                         float dt)
+{
+    if (n == 0) return GPE_OK;
+    Scope s(c, "Particle integration pass");  // particle_integration.rs:81
+    const VerletParams P = verlet_params(c, dt);
     uint64_t pairs = (n + 1) >> 1;
     hipLaunchKernelGGL(k_verlet, dim3(stream_grid(pairs)), dim3(kStreamBlock), 0, c->stream, pos, prev,
                        radius, n, P);

@@ -39,7 +39,7 @@ class Context:
         cfg.world_width, cfg.world_height = world
         cfg.gravity_x, cfg.gravity_y = gravity
         cfg.mode = mode
-        cfg.profiling = 1 if profiling else 0
+        cfg.profiling = int(profiling)
         h = C.c_void_p()
         L.check(self.lib.gpe_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -86,7 +86,8 @@ class Context:
         self.call("gpe_reset_timings")
 
     def set_profiling(self, on):
-        self.call("gpe_set_profiling", 1 if on else 0)
+        """False/0 off, True/1 every scope, k > 1: the scopes of every k-th step only (sampled)."""
+        self.call("gpe_set_profiling", int(on))
 
 
 class GpuBuffer:

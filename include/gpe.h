@@ -63,7 +63,7 @@ typedef struct gpe_config {
     float    stiffness;            /* collision_solver.wgsl:2  STIFFNESS = 0.6                */
     float    mouse_strength;       /* particle_integration.wgsl:22  = 150                     */
     uint32_t mode;                 /* GPE_MODE_*                                              */
-    uint32_t profiling;            /* 1: hipEvent pair around every scope (gpe_get_timings)   */
+    uint32_t profiling;            /* as gpe_set_profiling: 0 off, 1 every scope, k every k-th step */
     uint32_t reserved[5];
 } gpe_config;
 
@@ -211,6 +211,8 @@ typedef struct gpe_timing {
     double   total_ms;    /* sum over calls since the last gpe_reset_timings                  */
     uint64_t calls;
 } gpe_timing;
+/* on = 0: off; 1: every scope of every call; k > 1: the scopes of every k-th step only (sampled --
+   an event pair per kernel costs about as much as a small kernel). */
 gpe_status gpe_set_profiling(gpe_ctx *ctx, uint32_t on);
 gpe_status gpe_reset_timings(gpe_ctx *ctx);
 /* Synchronises, then writes up to *count entries; *count receives the number available. */

@@ -186,7 +186,7 @@ def test_native_spill_arena_is_exact(gpe, oracle, monkeypatch):
         st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
     _assert_positions(st.positions(), sim.pos, "over-dense scene through the spill arena")
     st.ctx.sync()
-    assert st.ctx.timings()["native/collide"][1] == 3
+    assert st.ctx.timings()["native/collide+verlet"][1] == 3
     st.close(); sim.close()
 
 
