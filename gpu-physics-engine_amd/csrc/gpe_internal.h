@@ -131,6 +131,27 @@ __device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t
     return base + inc - v;
 }
 
+// LDS words shared by the lanes of ONE wave between barriers-free steps (per-wave counters, match tables).
+// Not `volatile`: volatile accesses are left in the generic address space (flat_load/flat_store ... sc0 sc1
+// followed by s_waitcnt vmcnt(0)), several times the cost of ds_read/ds_write.  Relaxed wavefront-scope atomics
+// compile to plain ds_* instructions; wave_lds_order() keeps the compiler from moving them across each other
+// (the LDS itself executes a wave's instructions in order).
+template <typename T>
+__device__ __forceinline__ T wave_lds_load(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+template <typename T>
+__device__ __forceinline__ void wave_lds_store(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // LDS histogram add for one wave-round: one atomic when the whole wave holds one digit (the common
 // case for the high digits of nearly sorted keys), else one atomic per lane.
 __device__ __forceinline__ void hist_add(uint32_t *s_hist, uint32_t d, bool valid)

@@ -727,6 +727,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
         const int lx = home % RW, ly = home / RW;
         if (lx >= kHalo && lx < kHalo + T && ly >= kHalo && ly < kHalo + T) {
             uint32_t id = S.id[s];
+            asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if (A.order_keys) {                                        // S.id holds the order key: find the
                 int lo = 0, hi = NBLK;                                 // slot's block, re-read the local index
                 while (hi - lo > 1) {

@@ -4,7 +4,7 @@
 //      with one global atomic per bin per workgroup).  The native step fuses this into the cell-hash
 //      kernel (k_native.hip), so the keys are not even re-read.
 //   2. k_os_prepare turns the histograms into exclusive digit bases and resets the tile tickets.
-//   3. One kernel per digit: a workgroup takes a tile ticket, ranks its 4096 keys with wave64 ballots
+//   3. One kernel per digit: a workgroup takes a tile ticket, ranks its 8192 keys (lanes of a digit meet in an LDS match table)
 //      (stable), publishes its per-digit tile counts, resolves the counts of all preceding tiles by
 //      decoupled look-back over 8-byte {epoch, flag, value} status words, reorders the tile in LDS and
 //      writes each digit's run as one coalesced store.  Per pass: R 8 B + W 8 B per pair.
@@ -55,22 +55,6 @@ constexpr uint64_t kFlagPrefix = 2ull;           // value = count of the digit i
 constexpr uint32_t kSpinLimit = 1u << 24;
 
 typedef unsigned long long u64;
-
-__device__ __forceinline__ uint64_t os_match_digit(uint32_t d, bool valid)
-{
-    uint64_t m = __ballot(valid);
-    // whole wave on one digit (the usual case for the high digits of nearly sorted keys)
-    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane(
-        (int)d, __builtin_amdgcn_readfirstlane(m ? (int)__builtin_ctzll(m) : 0));
-    if (__ballot(valid && d != d0) == 0) return m;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
-    }
-    return m;
-}
 
 // 1. all four digit histograms in one read of the keys: hist4[p*256 + d]
 __global__ __launch_bounds__(kStreamBlock) void k_os_hist4(const uint32_t *__restrict__ keys, uint64_t n,
@@ -162,6 +146,7 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
 {
     __shared__ uint32_t s_stage[kOsTile];
     __shared__ uint32_t s_whist[kOsWaves][256];
+    __shared__ u64 s_match[kOsWaves][256];                         // per-wave digit -> lane mask, zero between rounds
     __shared__ uint32_t s_excl[256];
     __shared__ uint32_t s_delta[256];
     __shared__ uint32_t s_w[kOsWaves];
@@ -171,7 +156,7 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
     long long _t_prev = clock64();
 #endif
     if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[pass], 1u);     // ticket: tiles start in ticket order
-    for (int i = threadIdx.x; i < kOsWaves * 256; i += kOsBlock) (&s_whist[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < kOsWaves * 256; i += kOsBlock) { (&s_whist[0][0])[i] = 0; (&s_match[0][0])[i] = 0ull; }
     __syncthreads();
     const uint32_t tile = s_tile;
 
@@ -197,19 +182,47 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
 #endif
     // Rank: (round k, lane) is the input order inside the wave's span, so
     // rank = keys of this digit in earlier rounds + lower lanes of this round  => stable.
-    volatile uint32_t *wh = s_whist[w];
+    // Rank: (round k, lane) is the input order inside the wave's span, so
+    // rank = keys of this digit in earlier rounds + lower lanes of this round  => stable.
+    // The lanes of a round that share a digit find each other through LDS: every lane ORs its lane bit into
+    // its digit's 64-bit word of the wave's match table, reads the word back (the LDS runs a wave's
+    // instructions in order, so the read sees the whole round), and clears it for the next round.  That is 3
+    // LDS operations and ~10 VALU instructions per key where eight ballot-and-select steps took ~70 VALU
+    // instructions -- the pass was VALU-bound on those.
+    uint32_t *wh = s_whist[w];
+    u64 *wm = s_match[w];
+    const u64 my_bit = 1ull << lane;
+    constexpr int kBatch = 8;                                      // rounds whose match words are in flight together
 #pragma unroll
-    for (int k = 0; k < kOsItems; ++k) {
-        const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
-        const bool valid = idx < n;
-        const uint32_t d = (key[k] >> shift) & 255u;
-        const uint64_t m = os_match_digit(d, valid);
-        const uint32_t below = popc_below_lane(m);
-        const uint32_t pre = wh[d];
-        __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        slot[k] = (uint16_t)(pre + below);
+    for (int k0 = 0; k0 < kOsItems; k0 += kBatch) {
+        // OR / read / clear of a round do not wait for each other's results: the LDS keeps a wave's
+        // instructions in order, so a batch is issued back to back and its reads return together
+        u64 m[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int k = k0 + j;
+            const bool valid = wave_base + (uint64_t)k * 64 + lane < n;
+            const uint32_t d = (key[k] >> shift) & 255u;
+            if (valid) __hip_atomic_fetch_or(&wm[d], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            wave_lds_order();
+            m[j] = valid ? wave_lds_load(&wm[d]) : 0ull;
+            wave_lds_order();
+            if (valid) wave_lds_store(&wm[d], 0ull);
+            wave_lds_order();
+        }
+        // the per-wave digit counters: one dependent LDS read -> write per round
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int k = k0 + j;
+            const bool valid = wave_base + (uint64_t)k * 64 + lane < n;
+            const uint32_t d = (key[k] >> shift) & 255u;
+            const uint32_t below = (uint32_t)__popcll(m[j] & (my_bit - 1ull));
+            const uint32_t pre = wave_lds_load(&wh[d]);
+            wave_lds_order();
+            if (valid && below == 0) wave_lds_store(&wh[d], pre + (uint32_t)__popcll(m[j]));
+            wave_lds_order();
+            slot[k] = (uint16_t)(pre + below);
+        }
     }
     __syncthreads();
     OS_STAMP(1);

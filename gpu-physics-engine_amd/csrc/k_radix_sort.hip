@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const uint32_t *__r
 
     uint32_t key[kSortItems], val[kSortItems];
     uint16_t rank[kSortItems];
-    volatile uint32_t *wh = s_whist[w];
+    uint32_t *wh = s_whist[w];
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
@@ -103,10 +103,10 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const uint32_t *__r
         const uint32_t d = (key[k] >> shift) & 255u;
         const uint64_t m = match_digit(d, valid);
         const uint32_t below = popc_below_lane(m);
-        const uint32_t pre = wh[d];                       // all lanes of the group read the same word
-        __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(m);   // group leader publishes
-        __builtin_amdgcn_wave_barrier();
+        const uint32_t pre = wave_lds_load(&wh[d]);       // all lanes of the group read the same word
+        wave_lds_order();
+        if (valid && below == 0) wave_lds_store(&wh[d], pre + (uint32_t)__popcll(m));   // group leader publishes
+        wave_lds_order();
         rank[k] = (uint16_t)(pre + below);
     }
     __syncthreads();
