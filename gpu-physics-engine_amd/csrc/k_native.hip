@@ -327,7 +327,7 @@ struct TileLds {
         uint8_t sblk[CAP];     // P0-P1 only: region block a staged slot came from
     };
     uint16_t list[4 * QZ];     // active cells, one segment per colour
-    uint32_t lcnt[4];
+    uint32_t lcnt[8];          // per colour: [c] cells resolved by one lane, [4 + c] cells resolved by a lane group
     uint32_t bstart[NBLK];
     uint32_t bcnt[NBLK];
     uint32_t boff[NBLK + 1];
@@ -361,7 +361,7 @@ struct TileGlobal {
     __device__ __forceinline__ void cell_set(int i, uint32_t v) { cell[i] = v; }
     __device__ __forceinline__ uint32_t cell_inc(int i) { return atomicAdd(&cell[i], 1u); }
     uint16_t list[4 * QZ];
-    uint32_t lcnt[4];
+    uint32_t lcnt[8];          // per colour: [c] cells resolved by one lane, [4 + c] cells resolved by a lane group
     uint32_t bstart[NBLK];
     uint32_t bcnt[NBLK];
     uint32_t boff[NBLK + 1];
@@ -389,6 +389,25 @@ __device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint3
         if (ch) { S.mem[b] = m0; S.mem[b + 1] = m1; S.mem[b + 2] = m2; }
         return;
     }
+    if (n <= 8) {
+        // 4..8 members: rank count (ids are distinct) -- two LDS round trips whatever the order, where an
+        // insertion sort walks a dependent LDS chain per element; the colour pass waits for its slowest cell
+        constexpr int M = 8;
+        uint32_t slot[M], id[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) slot[k] = ((uint32_t)k < n) ? (uint32_t)S.mem[b + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < M; ++k) id[k] = ((uint32_t)k < n) ? S.id[slot[k]] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            uint32_t rank = 0;
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j != k) rank += (id[j] < id[k]) ? 1u : 0u;
+            if ((uint32_t)k < n && rank != (uint32_t)k) S.mem[b + rank] = slot[k];
+        }
+        return;
+    }
     for (uint32_t i = b + 1; i < e; ++i) {                             // insertion sort
         const uint32_t x = S.mem[i];
         const uint32_t kx = S.id[x];
@@ -404,7 +423,9 @@ __device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint3
 //    every pair touches a different partner, so that position cannot change in between;
 //  * inv_mass_1 (:103) is the same value for every pair of `a` and is computed once;
 //  * r1 == r2 (and 1/r finite, non-zero): inv1 == inv2 and inv1 + inv1 == 2*inv1 exactly, so both
-//    weights (:107-108) are exactly 0.5 -- the three divisions are skipped, not approximated.
+//    weights (:107-108) are exactly 0.5 -- the three divisions are skipped, not approximated;
+//  * q = vx*vx + vy*vy > 1.000001 * rs*rs implies rs*rs <= distance*distance (distance = sqrt(q) correctly
+//    rounded, so distance*distance >= q * (1 - 2^-22)): no collision (:95), and the square root is skipped.
 template <class L>
 __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint32_t e, const float stiffness)
 {
@@ -422,9 +443,12 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
             const float p2x = nx, p2y = ny, r2 = nr;                  // :86 live position
             if (ib + 1 < e) { nb = S.mem[ib + 1]; nx = S.px[nb]; ny = S.py[nb]; nr = S.rad[nb]; }
             const float vx = p1x - p2x, vy = p1y - p2y;               // :91
-            const float distance = sqrtf(vx * vx + vy * vy);          // :93
+            const float q = vx * vx + vy * vy;
             const float radius_sum = r1 + r2;                         // :61
-            if (radius_sum * radius_sum > distance * distance && distance > 0.0001f) {   // :95
+            const float rs2 = radius_sum * radius_sum;
+            if (q > rs2 * 1.000001f) continue;                        // no collision, see above: sqrt skipped
+            const float distance = sqrtf(q);                          // :93
+            if (rs2 > distance * distance && distance > 0.0001f) {    // :95
                 const float depth = radius_sum - distance;            // :97
                 const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
                 const float cy = ((vy / distance) * depth) * stiffness;
@@ -447,9 +471,76 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
     }
 }
 
+// A cell of 4..8 members resolved by kGroupLanes consecutive lanes of one wave.  The reference's pair sequence
+// (a, b), a < b in ascending object index (:68-118) only orders pairs that share a particle; pair (a, b) can
+// run as soon as (a, b-1) and (a-1, b) are done, i.e. at step a + b - 1 of a wavefront schedule -- 2n - 3 steps
+// instead of n (n-1) / 2, every particle still seeing its updates in the reference's order.  Lane a owns
+// particle a: it keeps p_a in registers from its first pair (a, a+1) to its last (a, n-1) -- nobody else
+// touches p_a in that window -- and updates its partner p_b in LDS, where lane a+1 picks it up one step later
+// (same wave: lockstep, and the LDS runs a wave's instructions in order).  Same arithmetic per pair as
+// resolve_cell, so the same bits.  The colour pass lasts as long as its slowest cell: this is what shortens it.
+constexpr uint32_t kGroupLanes = 8, kGroupMin = 4;
+template <class L>
+__device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint32_t n, const int a,
+                                              const float stiffness)
+{
+    // order the members: rank = members with a smaller object index (they are distinct)
+    const bool has = (uint32_t)a < n;
+    const uint32_t my_slot = has ? (uint32_t)S.mem[b + a] : 0u;
+    const uint32_t my_id = has ? S.id[my_slot] : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int i = 0; i < (int)kGroupLanes; ++i) rank += ((uint32_t)__shfl((int)my_id, i, kGroupLanes) < my_id) ? 1u : 0u;
+    // forward permute: lane r receives the slot of the member of rank r
+    const int group_base = lane_id() & ~((int)kGroupLanes - 1);
+    const uint32_t a_slot = (uint32_t)__builtin_amdgcn_ds_permute((group_base + (int)(has ? rank : (uint32_t)a)) << 2,
+                                                                  (int)my_slot);
+    float p1x = 0.f, p1y = 0.f, r1 = 1.f;
+    bool r1_plain = false, dirty = false;
+    const int last = 2 * (int)n - 4;
+    uint32_t b_slot = (uint32_t)__shfl((int)a_slot, (a + 1) & ((int)kGroupLanes - 1), kGroupLanes);
+    for (int t = 0; t <= last; ++t) {
+        const int bb = t - a + 1;                                     // this lane's partner at step t
+        const uint32_t cur = b_slot;
+        b_slot = (uint32_t)__shfl((int)a_slot, (bb + 1) & ((int)kGroupLanes - 1), kGroupLanes);   // next step's
+        if (bb <= a || bb >= (int)n) continue;
+        if (bb == a + 1) {                                            // first pair: p_a is final from lower lanes
+            p1x = S.px[a_slot]; p1y = S.py[a_slot]; r1 = S.rad[a_slot];
+            r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
+        }
+        const float p2x = S.px[cur], p2y = S.py[cur], r2 = S.rad[cur];    // :86 live position
+        const float vx = p1x - p2x, vy = p1y - p2y;                   // :91
+        const float q = vx * vx + vy * vy;
+        const float radius_sum = r1 + r2;                             // :61
+        const float rs2 = radius_sum * radius_sum;
+        if (q <= rs2 * 1.000001f) {                                   // else: no collision (see resolve_cell)
+            const float distance = sqrtf(q);                          // :93
+            if (rs2 > distance * distance && distance > 0.0001f) {    // :95
+                const float depth = radius_sum - distance;            // :97
+                const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
+                const float cy = ((vy / distance) * depth) * stiffness;
+                float w1, w2;
+                if (r1 == r2 && r1_plain) {
+                    w1 = 0.5f; w2 = 0.5f;                             // == inv1 / (inv1 + inv1), exactly
+                } else {
+                    const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;   // :103,104
+                    w1 = inv1 / (inv1 + inv2);                        // :107
+                    w2 = inv2 / (inv1 + inv2);                        // :108
+                }
+                p1x = p1x + cx * w1;                                  // :110
+                p1y = p1y + cy * w1;
+                S.px[cur] = p2x - cx * w2;                            // :111
+                S.py[cur] = p2y - cy * w2;
+                dirty = true;
+            }
+        }
+        if (bb == (int)n - 1 && dirty) { S.px[a_slot] = p1x; S.py[a_slot] = p1y; }
+    }
+}
+
 // One tile: returns false when the region exceeds the window's capacity (nothing written).
 template <class L>
-__device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
+__device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
 {
     constexpr int T = L::TILE;
     constexpr int RW = L::RW, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
@@ -461,7 +552,7 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
     S.cell_clear(tid);
-    if (tid < 4) S.lcnt[tid] = 0;
+    if (tid < 8) S.lcnt[tid] = 0;
     if (tid < NBLK) {
         const int bi = tid % NB, bj = tid / NB;
         const int bx = (ox >> 3) + bi, by = (oy >> 3) + bj;           // ox, oy are multiples of 8
@@ -659,37 +750,52 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
     __syncthreads();
     GPE_STAMP(3);
 
-    // ---- P4: active cells per colour.  Colour-major walk: every wave round looks at 64 cells of ONE
-    //          colour, so one ballot and one LDS atomic per round compact them ---------------------------
+    // ---- P4: active cells per colour.  Colour-major walk: every wave round looks at 64 cells of EACH colour
+    //          (the four colours' reads are in flight together), so one ballot and one LDS atomic per colour,
+    //          class and round compact them -------------------------------------------------------------
     {
         constexpr int HW = RW / 2, QC = NCELL / 4, QZ = L::QZ;        // cells of one colour: HW x HW
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-            // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox, oy are even
-            const int px0 = c & 1, py0 = c >> 1;
-            for (int base = 0; base < QC; base += kNatThreads) {
-                const int i = base + tid;
-                bool act = false;
-                int lc = 0;
-                if (i < QC) {
-                    const int lx = 2 * (i % HW) + px0, ly = 2 * (i / HW) + py0;
-                    lc = ly * RW + lx;
-                    const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
-                    const int gxx = ox + lx, gyy = oy + ly;
-                    const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
-                    const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
-                    // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
-                    // (collision_cell_builder.wgsl:56); cells outside the colour's exactness zone are skipped
-                    const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
-                    act = (e - b >= 2) && !unused_alias && (max(ex, ey) <= 4 - c);
+        for (int base = 0; base < QC; base += kNatThreads) {
+            const int i = base + tid;
+            const int hx = 2 * (i % HW), hy = 2 * (i / HW);
+            int lc[4];
+            uint32_t cnt[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox, oy are even
+                lc[c] = (hy + (c >> 1)) * RW + hx + (c & 1);
+                cnt[c] = 0;
+                if (i < QC) cnt[c] = S.cell_get(lc[c] + 1) - S.cell_get(lc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int lx = hx + (c & 1), ly = hy + (c >> 1);
+                const int gxx = ox + lx, gyy = oy + ly;
+                const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
+                const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
+                // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
+                // (collision_cell_builder.wgsl:56); cells outside the colour's exactness zone are skipped
+                const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
+                const bool act = (cnt[c] >= 2) && !unused_alias && (max(ex, ey) <= 4 - c);
+                const bool grp = act && (cnt[c] >= kGroupMin) && (cnt[c] <= kGroupLanes);
+                // cells of 4..8 members go to the BACK of the colour's segment: they are resolved by a group
+                // of 8 lanes (resolve_group); the others fill the segment from the front (one lane each)
+                const uint64_t mg = __ballot(grp);
+                const uint64_t ms = __ballot(act && !grp);
+                if (ms != 0) {
+                    const int leader = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(ms));
+                    uint32_t basei = 0;
+                    if (lane == leader) basei = atomicAdd(&S.lcnt[c], (uint32_t)__popcll(ms));
+                    basei = (uint32_t)__builtin_amdgcn_readlane((int)basei, leader);
+                    if (act && !grp) S.list[c * QZ + basei + popc_below_lane(ms)] = (uint16_t)lc[c];
                 }
-                const uint64_t m = __ballot(act);
-                if (m == 0) continue;
-                const int leader = (int)__builtin_ctzll(m);
-                uint32_t basei = 0;
-                if (lane == leader) basei = atomicAdd(&S.lcnt[c], (uint32_t)__popcll(m));
-                basei = __shfl(basei, leader, 64);
-                if (act) S.list[c * QZ + basei + popc_below_lane(m)] = (uint16_t)lc;
+                if (mg != 0) {
+                    const int leader = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mg));
+                    uint32_t basei = 0;
+                    if (lane == leader) basei = atomicAdd(&S.lcnt[4 + c], (uint32_t)__popcll(mg));
+                    basei = (uint32_t)__builtin_amdgcn_readlane((int)basei, leader);
+                    if (grp) S.list[c * QZ + (QZ - 1) - (basei + popc_below_lane(mg))] = (uint16_t)lc[c];
+                }
             }
         }
     }
@@ -704,12 +810,21 @@ __device__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int
 #endif
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        const uint32_t nk = S.lcnt[k];
-        for (uint32_t i = tid; i < nk; i += kNatThreads) {
-            const int lc = S.list[k * L::QZ + i];
-            const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
-            sort_members(S, b, e);
-            resolve_cell(S, b, e, A.stiffness);
+        const uint32_t ns = S.lcnt[k], group_lanes = S.lcnt[4 + k] * kGroupLanes;
+        const uint32_t single_base = (group_lanes + 63u) & ~63u;      // waves are all-group or all-single
+        const uint32_t work = single_base + ns;
+        for (uint32_t i0 = 0; i0 < work; i0 += kNatThreads) {
+            const uint32_t i = i0 + (uint32_t)tid;
+            if (i < group_lanes) {
+                const int lc = S.list[k * L::QZ + (L::QZ - 1) - (i / kGroupLanes)];
+                const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
+                resolve_group(S, b, e - b, (int)(i % kGroupLanes), A.stiffness);
+            } else if (i >= single_base && i < work) {
+                const int lc = S.list[k * L::QZ + (i - single_base)];
+                const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
+                sort_members(S, b, e);
+                resolve_cell(S, b, e, A.stiffness);
+            }
         }
 #ifdef GPE_TILE_STAMPS
         GPE_STAMP(9 + k);
