@@ -474,12 +474,28 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
 // A cell of 4..8 members resolved by kGroupLanes consecutive lanes of one wave.  The reference's pair sequence
 // (a, b), a < b in ascending object index (:68-118) only orders pairs that share a particle; pair (a, b) can
 // run as soon as (a, b-1) and (a-1, b) are done, i.e. at step a + b - 1 of a wavefront schedule -- 2n - 3 steps
-// instead of n (n-1) / 2, every particle still seeing its updates in the reference's order.  Lane a owns
-// particle a: it keeps p_a in registers from its first pair (a, a+1) to its last (a, n-1) -- nobody else
-// touches p_a in that window -- and updates its partner p_b in LDS, where lane a+1 picks it up one step later
-// (same wave: lockstep, and the LDS runs a wave's instructions in order).  Same arithmetic per pair as
-// resolve_cell, so the same bits.  The colour pass lasts as long as its slowest cell: this is what shortens it.
+// instead of n (n-1) / 2, every particle still seeing its updates in the reference's order.
+// The lanes form a systolic array: lane a owns particle a (registers); particle b enters at lane 0 at step
+// b - 1, meets one owner per step -- pair (a, b) at lane a -- and moves one lane up through a DPP row shift
+// until it reaches lane b, where it becomes that lane's own particle one step before its first pair (b, b+1).
+// Lane 0 is fed by a second pipe running down the lanes.  No LDS access inside the loop; same arithmetic per
+// pair as resolve_cell, so the same bits.  A colour pass
+// lasts as long as its slowest cell: this is what shortens it.
 constexpr uint32_t kGroupLanes = 8, kGroupMin = 4;
+__device__ __forceinline__ float dpp_from_lane_below(float v)
+{
+    // row_shr:1 -- lane i of a 16-lane row reads lane i - 1 (lane 0 of the row reads 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int dpp_from_lane_below(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float dpp_from_lane_above(float v)
+{
+    // row_shl:1 -- lane i of a 16-lane row reads lane i + 1 (the last lane of the row reads 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true));
+}
 template <class L>
 __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint32_t n, const int a,
                                               const float stiffness)
@@ -495,46 +511,58 @@ __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint
     const int group_base = lane_id() & ~((int)kGroupLanes - 1);
     const uint32_t a_slot = (uint32_t)__builtin_amdgcn_ds_permute((group_base + (int)(has ? rank : (uint32_t)a)) << 2,
                                                                   (int)my_slot);
-    float p1x = 0.f, p1y = 0.f, r1 = 1.f;
-    bool r1_plain = false, dirty = false;
-    const int last = 2 * (int)n - 4;
-    uint32_t b_slot = (uint32_t)__shfl((int)a_slot, (a + 1) & ((int)kGroupLanes - 1), kGroupLanes);
+    // step-start state of the lane's particle; also what lane 0 is fed with (nothing touches particle b before
+    // its first pair (0, b))
+    float ox = 0.f, oy = 0.f, r1 = 1.f;
+    if (has) { ox = S.px[a_slot]; oy = S.py[a_slot]; r1 = S.rad[a_slot]; }
+    float p1x = ox, p1y = oy;
+    const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
+    float qx = 0.f, qy = 0.f, qr = 1.f;                               // the particle this lane passes on
+    int qb = -1;                                                      // ... its index in the cell, -1: none
+    const int last = 2 * (int)n - 3;
+    // the feed: a second pipe running DOWN the lanes, one lane per step, primed so that lane 0 finds particle
+    // t + 1 in it at step t (what arrives from beyond the cell's lanes is never used: ib < n)
+    float fx = dpp_from_lane_above(ox), fy = dpp_from_lane_above(oy), fr = dpp_from_lane_above(r1);
     for (int t = 0; t <= last; ++t) {
-        const int bb = t - a + 1;                                     // this lane's partner at step t
-        const uint32_t cur = b_slot;
-        b_slot = (uint32_t)__shfl((int)a_slot, (bb + 1) & ((int)kGroupLanes - 1), kGroupLanes);   // next step's
-        if (bb <= a || bb >= (int)n) continue;
-        if (bb == a + 1) {                                            // first pair: p_a is final from lower lanes
-            p1x = S.px[a_slot]; p1y = S.py[a_slot]; r1 = S.rad[a_slot];
-            r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
-        }
-        const float p2x = S.px[cur], p2y = S.py[cur], r2 = S.rad[cur];    // :86 live position
-        const float vx = p1x - p2x, vy = p1y - p2y;                   // :91
-        const float q = vx * vx + vy * vy;
-        const float radius_sum = r1 + r2;                             // :61
-        const float rs2 = radius_sum * radius_sum;
-        if (q <= rs2 * 1.000001f) {                                   // else: no collision (see resolve_cell)
-            const float distance = sqrtf(q);                          // :93
-            if (rs2 > distance * distance && distance > 0.0001f) {    // :95
-                const float depth = radius_sum - distance;            // :97
-                const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
-                const float cy = ((vy / distance) * depth) * stiffness;
-                float w1, w2;
-                if (r1 == r2 && r1_plain) {
-                    w1 = 0.5f; w2 = 0.5f;                             // == inv1 / (inv1 + inv1), exactly
-                } else {
-                    const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;   // :103,104
-                    w1 = inv1 / (inv1 + inv2);                        // :107
-                    w2 = inv2 / (inv1 + inv2);                        // :108
+        float ix = dpp_from_lane_below(qx), iy = dpp_from_lane_below(qy), ir = dpp_from_lane_below(qr);
+        int ib = dpp_from_lane_below(qb);
+        if (a == 0) { ix = fx; iy = fy; ir = fr; ib = (t + 1 < (int)n) ? t + 1 : -1; }
+        fx = dpp_from_lane_above(fx); fy = dpp_from_lane_above(fy); fr = dpp_from_lane_above(fr);
+        qb = -1;
+        if (ib == a) {                                                // the lane's own particle has arrived
+            p1x = ix; p1y = iy;
+        } else if (ib > a && has) {                                   // pair (a, ib), step t == a + ib - 1
+            const float r2 = ir;
+            const float vx = p1x - ix, vy = p1y - iy;                 // :91 (live positions, :86)
+            const float q = vx * vx + vy * vy;
+            const float radius_sum = r1 + r2;                         // :61
+            const float rs2 = radius_sum * radius_sum;
+            if (q <= rs2 * 1.000001f) {                               // else: no collision (see resolve_cell)
+                const float distance = sqrtf(q);                      // :93
+                if (rs2 > distance * distance && distance > 0.0001f) {    // :95
+                    const float depth = radius_sum - distance;        // :97
+                    const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
+                    const float cy = ((vy / distance) * depth) * stiffness;
+                    float w1, w2;
+                    if (r1 == r2 && r1_plain) {
+                        w1 = 0.5f; w2 = 0.5f;                         // == inv1 / (inv1 + inv1), exactly
+                    } else {
+                        const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;   // :103,104
+                        w1 = inv1 / (inv1 + inv2);                    // :107
+                        w2 = inv2 / (inv1 + inv2);                    // :108
+                    }
+                    p1x = p1x + cx * w1;                              // :110
+                    p1y = p1y + cy * w1;
+                    ix = ix - cx * w2;                                // :111
+                    iy = iy - cy * w2;
                 }
-                p1x = p1x + cx * w1;                                  // :110
-                p1y = p1y + cy * w1;
-                S.px[cur] = p2x - cx * w2;                            // :111
-                S.py[cur] = p2y - cy * w2;
-                dirty = true;
             }
+            qx = ix; qy = iy; qr = ir; qb = ib;
         }
-        if (bb == (int)n - 1 && dirty) { S.px[a_slot] = p1x; S.py[a_slot] = p1y; }
+    }
+    if (has && (__float_as_uint(p1x) != __float_as_uint(ox) || __float_as_uint(p1y) != __float_as_uint(oy))) {
+        S.px[a_slot] = p1x;
+        S.py[a_slot] = p1y;
     }
 }
 
@@ -686,27 +714,40 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float lo_x = (float)(cx + i - 1) * A.cell_size, lo_y = (float)(cy + i - 1) * A.cell_size;
-                const float dx = p.x - clamp_f(p.x, lo_x, lo_x + A.cell_size);
-                const float dy = p.y - clamp_f(p.y, lo_y, lo_y + A.cell_size);
+                // clamp as one v_med3_f32: equal to clamp_f for every non-NaN p (a zero of either sign squares
+                // to +0 below), and for a NaN p the difference is NaN whatever the clamp returns
+                const float dx = p.x - __builtin_amdgcn_fmed3f(p.x, lo_x, lo_x + A.cell_size);
+                const float dy = p.y - __builtin_amdgcn_fmed3f(p.y, lo_y, lo_y + A.cell_size);
                 sx[i] = dx * dx;
                 sy[i] = dy * dy;
             }
-            uint32_t code = 0, pc = 0;
+            // bit k of `over`: the k-th neighbour of the reference's scan (y outer, x inner, centre skipped)
+            // overlaps; the first three set bits are the phantom cells kept
+            uint32_t over = 0;
+            {
+                int k = 0;
 #pragma unroll
-            for (int y = -1; y <= 1; ++y) {
+                for (int y = -1; y <= 1; ++y) {
 #pragma unroll
-                for (int x = -1; x <= 1; ++x) {
-                    if (x == 0 && y == 0) continue;
-                    if (sx[x + 1] + sy[y + 1] < sq) {
-                        if (pc < 3) {
-                            code |= (uint32_t)((y + 1) * 3 + (x + 1)) << (4 * pc);
-                            const int nlx = lx + x, nly = ly + y;
-                            if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW)
-                                S.cell_inc(nly * RW + nlx + 1);
-                        }
-                        ++pc;
+                    for (int x = -1; x <= 1; ++x) {
+                        if (x == 0 && y == 0) continue;
+                        over |= (sx[x + 1] + sy[y + 1] < sq) ? (1u << k) : 0u;
+                        ++k;
                     }
                 }
+            }
+            const uint32_t pc = (uint32_t)__popc(over);
+            uint32_t code = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (over == 0) break;
+                const int k = __ffs((int)over) - 1;
+                over &= over - 1u;
+                const int nb = k + (k >> 2);                           // neighbour index (y+1)*3 + (x+1), 4 = centre
+                code |= (uint32_t)nb << (4 * j);
+                const int y3 = (nb * 11) >> 5;                         // nb / 3 for nb < 9
+                const int nlx = lx + (nb - 3 * y3) - 1, nly = ly + y3 - 1;
+                if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) S.cell_inc(nly * RW + nlx + 1);
             }
             S.hm[s] = (uint32_t)home | (code << 16) | ((pc < 3 ? pc : 3u) << 28);
         }
@@ -730,6 +771,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     GPE_STAMP(2);
 
     // ---- P3: fill the member lists (order fixed later by the per-cell sort) --------------------------
+#ifdef GPE_DBG_SKIP
+    if (!(GPE_DBG_SKIP & 4))
+#endif
     for (uint32_t s = tid; s < P; s += kNatThreads) {
         const uint32_t hm = S.hm[s];
         const int home = (int)(hm & 0xFFFFu);
@@ -750,14 +794,19 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     __syncthreads();
     GPE_STAMP(3);
 
+#ifdef GPE_DBG_SKIP
+    if (!(GPE_DBG_SKIP & 2))
+#endif
     // ---- P4: active cells per colour.  Colour-major walk: every wave round looks at 64 cells of EACH colour
     //          (the four colours' reads are in flight together), so one ballot and one LDS atomic per colour,
     //          class and round compact them -------------------------------------------------------------
     {
-        constexpr int HW = RW / 2, QC = NCELL / 4, QZ = L::QZ;        // cells of one colour: HW x HW
+        // only cells inside the widest exactness zone (tile +- 4 cells) can be active: (T + 8)^2 / 4 per colour
+        constexpr int ZW = (T + 8) / 2, QC = ZW * ZW, QZ = L::QZ;
+        static_assert(QC == QZ, "one list slot per zone cell of a colour");
         for (int base = 0; base < QC; base += kNatThreads) {
             const int i = base + tid;
-            const int hx = 2 * (i % HW), hy = 2 * (i / HW);
+            const int hx = 2 * (i % ZW) + (kHalo - 4), hy = 2 * (i / ZW) + (kHalo - 4);
             int lc[4];
             uint32_t cnt[4];
 #pragma unroll
@@ -808,6 +857,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #if GPE_P5_PRIO
     __builtin_amdgcn_s_setprio(GPE_P5_PRIO);
 #endif
+#ifdef GPE_DBG_SKIP
+    if (!(GPE_DBG_SKIP & 1))                                           // diagnostic builds: phase cost by omission
+#endif
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const uint32_t ns = S.lcnt[k], group_lanes = S.lcnt[4 + k] * kGroupLanes;
@@ -818,12 +870,20 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             if (i < group_lanes) {
                 const int lc = S.list[k * L::QZ + (L::QZ - 1) - (i / kGroupLanes)];
                 const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
+#ifdef GPE_DBG_SKIP
+                if (!(GPE_DBG_SKIP & 8))
+#endif
                 resolve_group(S, b, e - b, (int)(i % kGroupLanes), A.stiffness);
             } else if (i >= single_base && i < work) {
                 const int lc = S.list[k * L::QZ + (i - single_base)];
                 const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
-                sort_members(S, b, e);
-                resolve_cell(S, b, e, A.stiffness);
+#ifdef GPE_DBG_SKIP
+                if (!(GPE_DBG_SKIP & 16))
+#endif
+                {
+                    sort_members(S, b, e);
+                    resolve_cell(S, b, e, A.stiffness);
+                }
             }
         }
 #ifdef GPE_TILE_STAMPS
