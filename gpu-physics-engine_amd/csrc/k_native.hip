@@ -99,7 +99,8 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_clear(uint4 *__restrict
 
 // ---------------------------------------------------------------------------------------------------
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
-// (home_cell_ids.wgsl:24-31 computes the same key; the particle id is implicit in the first pass.)
+// (home_cell_ids.wgsl:24-31 computes the Morton id of the home cell; the key kept here is the row-major index
+// of its 8x8-cell block; the particle id is implicit in the first pass.)
 // The workgroup that flushes its histogram last also turns the histograms into the digit bases of the four
 // passes and resets the tile tickets (k_os_prepare's job): one launch less on the step path.
 // ---------------------------------------------------------------------------------------------------
@@ -110,7 +111,7 @@ constexpr int kHashBlock = 1024;
 constexpr int kHashBatch = 8;                  // positions loaded per lane before any of them is ranked
 __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__restrict__ pos, uint64_t n,
                                                             float cell_size, int32_t gx, int32_t gy,
-                                                            uint32_t *__restrict__ keys, int digits,
+                                                            int32_t blocks_x, uint32_t *__restrict__ keys, int digits,
                                                             uint32_t *hist4, uint32_t *__restrict__ bases4,
                                                             uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl)
 {
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
             if (valid) {
                 const int32_t cx = cell_coord(p[u].x, cell_size), cy = cell_coord(p[u].y, cell_size);
                 oob |= (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy);
-                key = morton_encode(cx, cy);
+                // the particle's 8x8-cell block, row-major over the box (0 for a particle outside it: flagged)
+                key = ((cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy)) ? 0u : (uint32_t)((cy >> 3) * blocks_x + (cx >> 3));
                 keys[idx[u]] = key;
             }
 #pragma unroll
@@ -189,14 +191,15 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_window_max(const uint2 
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint32_t best = 0;
     for (uint64_t mb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; mb < entries; mb += stride) {
-        const int bx = (int)unsplit_by_bits((uint32_t)mb), by = (int)unsplit_by_bits((uint32_t)mb >> 1);
+        const int blocks_x = (gx + 7) >> 3;
+        const int bx = (int)(mb % (uint32_t)blocks_x), by = (int)(mb / (uint32_t)blocks_x);
         if (bx * 8 >= gx || by * 8 >= gy) continue;
         uint32_t sum = 0;
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int x = bx + dx, y = by + dy;
                 if (x < 0 || y < 0 || x * 8 >= gx || y * 8 >= gy) continue;
-                const uint32_t m = morton_encode(x, y);
+                const uint32_t m = (uint32_t)(y * blocks_x + x);
                 if (m < entries) { const uint2 se = table[m]; sum += se.y - se.x; }
             }
         best = max(best, sum);
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_check_box(const float2 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// table: block b = key >> 6 (an aligned 8x8-cell block is contiguous in Morton order).
+// table: the sort key is the particle's 8x8-cell block (row-major index over the box).
 // table[b] = (first, one-past-last) position of the block's particles; empty blocks stay (0,0).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStreamBlock) void k_native_block_table(const uint32_t *__restrict__ sorted_keys,
@@ -230,10 +233,10 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_block_table(const uint3
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t b = sorted_keys[i] >> 6;
+        const uint32_t b = sorted_keys[i];
         if (b >= entries) continue;
-        const bool first = (i == 0) || ((sorted_keys[i - 1] >> 6) != b);
-        const bool last = (i + 1 == n) || ((sorted_keys[i + 1] >> 6) != b);
+        const bool first = (i == 0) || (sorted_keys[i - 1] != b);
+        const bool last = (i + 1 == n) || (sorted_keys[i + 1] != b);
         if (first) table[b].x = (uint32_t)i;
         if (last) table[b].y = (uint32_t)(i + 1);
     }
@@ -249,6 +252,7 @@ struct CollideArgs {
     const uint32_t *sorted_ids;
     const uint2 *table;
     uint32_t entries;
+    int32_t blocks_x;            // table index of block (bx, by) = by * blocks_x + bx
     float cell_size;
     float stiffness;
     int32_t gx, gy;              // cell box
@@ -586,7 +590,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         const int bx = (ox >> 3) + bi, by = (oy >> 3) + bj;           // ox, oy are multiples of 8
         uint32_t start = 0, count = 0;
         if (bx >= 0 && by >= 0 && bx * 8 < A.gx && by * 8 < A.gy) {
-            const uint32_t mb = morton_encode(bx, by);
+            const uint32_t mb = (uint32_t)(by * A.blocks_x + bx);
             if (mb < A.entries) {
                 const uint2 se = A.table[mb];
                 start = se.x;
@@ -1039,7 +1043,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
         // one workgroup per CU at most, at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
         const int grid = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
         hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, n,
-                           c->cell_size, N.gx, N.gy, N.keys, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl,
+                           c->cell_size, N.gx, N.gy, N.blocks_x, N.keys, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl,
                            N.tile_ctl);
         GPE_HIP(c, hipGetLastError());
     }
@@ -1074,12 +1078,17 @@ gpe_status native_configure(gpe_ctx *c)
     if (!(fx >= 0.0f) || !(fy >= 0.0f) || fx > 65000.0f || fy > 65000.0f) return GPE_OK;   // 16-bit cell coords
     N.gx = (int32_t)fx + 1;
     N.gy = (int32_t)fy + 1;
-    const uint32_t max_key = host_split((uint32_t)(N.gx - 1)) | (host_split((uint32_t)(N.gy - 1)) << 1);
+    // The sort key is the particle's 8x8-cell BLOCK, row-major over the box: the tiles look particles up per
+    // block and order the members of a cell themselves, so the order inside a block is free.  Against the
+    // Morton id of the home cell (what the reference sorts by) that is 6 bits less plus the padding Morton
+    // interleaving adds to a non-square box: one radix pass less at 1 M (2 instead of 3) and at 100 M (3 / 4).
+    N.blocks_x = (N.gx + 7) >> 3;
+    const uint32_t blocks_y = (uint32_t)((N.gy + 7) >> 3);
+    N.table_entries = (uint32_t)N.blocks_x * blocks_y;
     int bits = 0;
-    while (bits < 32 && (max_key >> bits) != 0) ++bits;
+    while (bits < 32 && ((N.table_entries - 1) >> bits) != 0) ++bits;
     N.passes = (bits + 7) / 8;
     if (N.passes < 1) N.passes = 1;
-    N.table_entries = (max_key >> 6) + 1;
     if (N.table_entries > (1u << 27)) return GPE_OK;                   // > 1 GiB of table: stay on compat
     if (N.table_cap < N.table_entries) {
         if (N.block_table) GPE_HIP(c, hipFree(N.block_table));
@@ -1188,6 +1197,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.sorted_ids = sorted_ids;
     A.table = N.block_table;
     A.entries = N.table_entries;
+    A.blocks_x = N.blocks_x;
     A.cell_size = c->cell_size;
     A.stiffness = c->cfg.stiffness;
     A.gx = N.gx;

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
     u64 *wm = s_match[w];
     const u64 my_bit = 1ull << lane;
     constexpr int kBatch = 8;                                      // rounds whose match words are in flight together
+    constexpr int kPeel = 4;                                       // digit values matched by ballot before the table
 #pragma unroll
     for (int k0 = 0; k0 < kOsItems; k0 += kBatch) {
         // OR / read / clear of a round do not wait for each other's results: the LDS keeps a wave's
@@ -203,12 +204,30 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
             const int k = k0 + j;
             const bool valid = wave_base + (uint64_t)k * 64 + lane < n;
             const uint32_t d = (key[k] >> shift) & 255u;
-            if (valid) __hip_atomic_fetch_or(&wm[d], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            wave_lds_order();
-            m[j] = valid ? wave_lds_load(&wm[d]) : 0ull;
-            wave_lds_order();
-            if (valid) wave_lds_store(&wm[d], 0ull);
-            wave_lds_order();
+            // Clustered digits (keys of neighbouring particles: a wave holds a handful of values) are peeled off
+            // with ballots, one value per step -- many lanes ORing into ONE LDS word serialise; what is left
+            // after kPeel values (scattered digits) meets through the LDS match table.
+            u64 rem = __ballot(valid);
+            u64 mine = 0ull;
+#pragma unroll
+            for (int it = 0; it < kPeel; ++it) {
+                if (rem == 0) break;                                   // wave-uniform
+                const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rem));
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+                const u64 same = __ballot(valid && d == d0) & rem;
+                if (d == d0) mine = same;
+                rem &= ~same;
+            }
+            const bool left = (rem >> lane) & 1ull;
+            if (rem != 0) {                                            // wave-uniform
+                if (left) __hip_atomic_fetch_or(&wm[d], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                wave_lds_order();
+                if (left) mine = wave_lds_load(&wm[d]);
+                wave_lds_order();
+                if (left) wave_lds_store(&wm[d], 0ull);
+                wave_lds_order();
+            }
+            m[j] = valid ? mine : 0ull;
         }
         // the per-wave digit counters: one dependent LDS read -> write per round
 #pragma unroll
