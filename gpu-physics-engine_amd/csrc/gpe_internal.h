@@ -158,7 +158,8 @@ __device__ __forceinline__ void hist_add(uint32_t *s_hist, uint32_t d, bool vali
 {
     // Only scalar work on the critical path (ballots, one v_readlane): either the whole wave holds one
     // digit value -- one atomic -- or every lane issues its own fire-and-forget LDS atomic (the LDS
-    // serialises lanes that hit the same bin, which costs less than finding them with cross-lane round trips).
+    // serialises lanes that hit the same bin; measured cheaper than peeling the values off with ballots:
+    // the hash kernel went from 0.44 to 0.70 ms at 100 M particles with a four-value peel).
     const uint64_t m = __ballot(valid);
     if (m == 0) return;                                        // wave-uniform
     const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));

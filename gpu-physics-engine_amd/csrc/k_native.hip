@@ -231,14 +231,29 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_block_table(const uint3
                                                                      uint64_t n, uint2 *__restrict__ table,
                                                                      uint32_t entries)
 {
+    // four consecutive keys per lane (one 16-byte load) + the two neighbours of the quad
+    const uint64_t quads = (n + 3) / 4;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t b = sorted_keys[i];
-        if (b >= entries) continue;
-        const bool first = (i == 0) || (sorted_keys[i - 1] != b);
-        const bool last = (i + 1 == n) || (sorted_keys[i + 1] != b);
-        if (first) table[b].x = (uint32_t)i;
-        if (last) table[b].y = (uint32_t)(i + 1);
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
+        const uint64_t i0 = q * 4;
+        uint32_t k[6];                                                 // keys i0-1 .. i0+4
+        if (i0 + 4 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(sorted_keys + i0);
+            k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[1 + j] = (i0 + j < n) ? sorted_keys[i0 + j] : 0xFFFFFFFFu;
+        }
+        k[0] = (i0 > 0) ? sorted_keys[i0 - 1] : 0xFFFFFFFFu;
+        k[5] = (i0 + 4 < n) ? sorted_keys[i0 + 4] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = i0 + j;
+            const uint32_t b = k[1 + j];
+            if (i >= n || b >= entries) continue;
+            if (i == 0 || k[j] != b) table[b].x = (uint32_t)i;
+            if (i + 1 == n || k[2 + j] != b) table[b].y = (uint32_t)(i + 1);
+        }
     }
 }
 
@@ -1054,7 +1069,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     }
     {
         Scope s(c, "native/table");
-        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid(n)), dim3(kStreamBlock), 0, c->stream, sk, n,
+        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid((n + 3) / 4)), dim3(kStreamBlock), 0, c->stream, sk, n,
                            N.block_table, N.table_entries);
         GPE_HIP(c, hipGetLastError());
     }
