@@ -243,6 +243,7 @@ struct NativeState {
     uint32_t *keys = nullptr, *ids = nullptr;       // N each: hash output / sort ping
     uint32_t *keys_b = nullptr, *ids_b = nullptr;   // sort pong
     uint64_t cap = 0;
+    uint16_t *codes = nullptr;       // per particle: cell inside its block | neighbour overlap mask (k_native_hash)
     int32_t blocks_x = 0;            // 8x8-cell blocks per row of the box: table index = by * blocks_x + bx
     uint32_t *tile_ctl = nullptr;    // device control words (k_native.hip kCtl*)
     uint32_t *overflow1 = nullptr;   // packed (ty << 16 | tx) of 32x32 tiles over capacity

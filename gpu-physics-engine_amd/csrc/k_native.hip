@@ -62,7 +62,6 @@ __device__ __forceinline__ uint32_t nat_block_exclusive_scan(uint32_t v, uint32_
 constexpr int kHalo = 8;                       // cells = one 8x8 Morton block
 constexpr uint32_t kErrOutOfBox = 1u;          // a particle outside the configured cell box
 constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS capacity (no result!)
-constexpr uint32_t kErrRegion = 4u;            // internal: particle outside its staged region
 // tile_ctl words (the first four are cleared every step, the error word is sticky)
 constexpr int kCtlOverflow1 = 0;               // 32x32 tiles over capacity this step
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
@@ -104,14 +103,48 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_clear(uint4 *__restrict
 // The workgroup that flushes its histogram last also turns the histograms into the digit bases of the four
 // passes and resets the tile tickets (k_os_prepare's job): one launch less on the step path.
 // ---------------------------------------------------------------------------------------------------
+// Which of the 8 neighbour cells does the particle overlap?  Bit k = the k-th neighbour of the reference's scan
+// (grid.wgsl:68-90: y outer, x inner, centre skipped).  is_obj_in_cell (grid.wgsl:117-129) per axis: the
+// clamped offset of neighbour column i / row j does not depend on the other axis, so the 8 tests share 3 + 3
+// squared offsets (same operations and order as dot(d, d) = d.x*d.x + d.y*d.y).
+__device__ __forceinline__ uint32_t neighbour_overlap_mask(float2 p, float r, int32_t cx, int32_t cy, float cell_size)
+{
+    const float sq = r * r;
+    float sx[3], sy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float lo_x = (float)(cx + i - 1) * cell_size, lo_y = (float)(cy + i - 1) * cell_size;
+        // clamp as one v_med3_f32: equal to clamp_f for every non-NaN p (a zero of either sign squares
+        // to +0 below), and for a NaN p the difference is NaN whatever the clamp returns
+        const float dx = p.x - __builtin_amdgcn_fmed3f(p.x, lo_x, lo_x + cell_size);
+        const float dy = p.y - __builtin_amdgcn_fmed3f(p.y, lo_y, lo_y + cell_size);
+        sx[i] = dx * dx;
+        sy[i] = dy * dy;
+    }
+    uint32_t over = 0;
+    int k = 0;
+#pragma unroll
+    for (int y = -1; y <= 1; ++y) {
+#pragma unroll
+        for (int x = -1; x <= 1; ++x) {
+            if (x == 0 && y == 0) continue;
+            over |= (sx[x + 1] + sy[y + 1] < sq) ? (1u << k) : 0u;
+            ++k;
+        }
+    }
+    return over;
+}
+
 // Every workgroup flushes up to 256 bins per digit with device-scope atomics (they resolve beyond the per-XCD
 // L2s): FEW, LARGE workgroups (1024 lanes, at most one per CU) keep the flush small however many particles
 // there are.
 constexpr int kHashBlock = 1024;
 constexpr int kHashBatch = 8;                  // positions loaded per lane before any of them is ranked
-__global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__restrict__ pos, uint64_t n,
+__global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__restrict__ pos,
+                                                            const float *__restrict__ radius, uint64_t n,
                                                             float cell_size, int32_t gx, int32_t gy,
-                                                            int32_t blocks_x, uint32_t *__restrict__ keys, int digits,
+                                                            int32_t blocks_x, uint32_t *__restrict__ keys,
+                                                            uint16_t *__restrict__ codes, int digits,
                                                             uint32_t *hist4, uint32_t *__restrict__ bases4,
                                                             uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl)
 {
@@ -125,11 +158,14 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
     bool oob = false;
     for (uint64_t r0 = 0; r0 < rounds; r0 += kHashBatch) {
         float2 p[kHashBatch];
+        float rad[kHashBatch];
         uint64_t idx[kHashBatch];
 #pragma unroll
         for (int u = 0; u < kHashBatch; ++u) {                        // the loads of a batch are in flight together
             idx[u] = (r0 + u) * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-            p[u] = (r0 + u < rounds && idx[u] < n) ? pos[idx[u]] : make_float2(0.f, 0.f);
+            const bool in = r0 + u < rounds && idx[u] < n;
+            p[u] = in ? pos[idx[u]] : make_float2(0.f, 0.f);
+            rad[u] = in ? radius[idx[u]] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < kHashBatch; ++u) {
@@ -142,6 +178,10 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
                 // the particle's 8x8-cell block, row-major over the box (0 for a particle outside it: flagged)
                 key = ((cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy)) ? 0u : (uint32_t)((cy >> 3) * blocks_x + (cx >> 3));
                 keys[idx[u]] = key;
+                // what the tiles need to file the particle: its cell inside the block and its phantom cells.
+                // Computed once here instead of by each of the ~2.25 tiles that stage the particle.
+                codes[idx[u]] = (uint16_t)((uint32_t)(cx & 7) | ((uint32_t)(cy & 7) << 3) |
+                                           (neighbour_overlap_mask(p[u], rad[u], cx, cy, cell_size) << 6));
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -265,6 +305,7 @@ struct CollideArgs {
     const float *radius;
     float2 *pos_out;
     const uint32_t *sorted_ids;
+    const uint16_t *codes;       // per particle: cell inside its block (6 bits) | neighbour overlap mask (8 bits)
     const uint2 *table;
     uint32_t entries;
     int32_t blocks_x;            // table index of block (bx, by) = by * blocks_x + bx
@@ -675,16 +716,16 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // ---- P1: gather the region's particles (all loads of a thread in flight together), count the
     //          cell memberships -----------------------------------------------------------------------
     for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QMAX * kNatThreads) {   // one round unless the window spills
-        uint32_t pid[QMAX];
+        uint32_t pid[QMAX], blk[QMAX], cc[QMAX];
         float2 pp[QMAX];
         float pr[QMAX];
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            pid[q] = 0;
+            pid[q] = 0; blk[q] = 0;
             if (s < P) {
-                const uint32_t b = S.sblk[s];
-                pid[q] = A.sorted_ids[S.bstart[b] + (s - S.boff[b])];
+                blk[q] = S.sblk[s];
+                pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
             }
         }
 #ifdef GPE_TILE_STAMPS
@@ -696,9 +737,11 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             pp[q] = make_float2(0.f, 0.f);
             pr[q] = 0.f;
+            cc[q] = 0;
             if (s < P) {
                 pp[q] = A.pos_in[pid[q]];
                 pr[q] = A.radius[pid[q]];
+                cc[q] = A.codes[pid[q]];
                 // sharded run: the member order is the particle's index in the unsharded system; the local
                 // index is looked up again at write-back (P6)
                 if (A.order_keys) pid[q] = A.order_keys[pid[q]];
@@ -712,49 +755,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         for (int q = 0; q < QMAX; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             if (s >= P) continue;
-            const float2 p = pp[q];
-            const float r = pr[q];
-            const int32_t cx = cell_coord(p.x, A.cell_size), cy = cell_coord(p.y, A.cell_size);
-            int lx = cx - ox, ly = cy - oy;
-            if (lx < 0 || lx >= RW || ly < 0 || ly >= RW) {            // cannot happen with a consistent table
-                atomicOr(&A.tile_ctl[kCtlError], kErrRegion);
-                lx = min(max(lx, 0), RW - 1);
-                ly = min(max(ly, 0), RW - 1);
-            }
-            S.px[s] = p.x; S.py[s] = p.y; S.rad[s] = r; S.id[s] = pid[q];
+            // home cell: the slot's block inside the region + the cell inside the block (k_native_hash)
+            const int lx = (int)(blk[q] % NB) * 8 + (int)(cc[q] & 7u), ly = (int)(blk[q] / NB) * 8 + (int)((cc[q] >> 3) & 7u);
+            S.px[s] = pp[q].x; S.py[s] = pp[q].y; S.rad[s] = pr[q]; S.id[s] = pid[q];
             const int home = ly * RW + lx;
             S.cell_inc(home + 1);
-            // phantom cells in the reference's scan order (grid.wgsl:68-90), at most three kept.
-            // is_obj_in_cell (grid.wgsl:117-129) per axis: the clamped offset of neighbour column i /
-            // row j does not depend on the other axis, so the 8 tests share 3 + 3 squared offsets
-            // (same operations and order as dot(d, d) = d.x*d.x + d.y*d.y).
-            const float sq = r * r;
-            float sx[3], sy[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float lo_x = (float)(cx + i - 1) * A.cell_size, lo_y = (float)(cy + i - 1) * A.cell_size;
-                // clamp as one v_med3_f32: equal to clamp_f for every non-NaN p (a zero of either sign squares
-                // to +0 below), and for a NaN p the difference is NaN whatever the clamp returns
-                const float dx = p.x - __builtin_amdgcn_fmed3f(p.x, lo_x, lo_x + A.cell_size);
-                const float dy = p.y - __builtin_amdgcn_fmed3f(p.y, lo_y, lo_y + A.cell_size);
-                sx[i] = dx * dx;
-                sy[i] = dy * dy;
-            }
-            // bit k of `over`: the k-th neighbour of the reference's scan (y outer, x inner, centre skipped)
-            // overlaps; the first three set bits are the phantom cells kept
-            uint32_t over = 0;
-            {
-                int k = 0;
-#pragma unroll
-                for (int y = -1; y <= 1; ++y) {
-#pragma unroll
-                    for (int x = -1; x <= 1; ++x) {
-                        if (x == 0 && y == 0) continue;
-                        over |= (sx[x + 1] + sy[y + 1] < sq) ? (1u << k) : 0u;
-                        ++k;
-                    }
-                }
-            }
+            // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
+            uint32_t over = cc[q] >> 6;
             const uint32_t pc = (uint32_t)__popc(over);
             uint32_t code = 0;
 #pragma unroll
@@ -1031,6 +1038,7 @@ void native_release(gpe_ctx *c)
     NativeState &N = c->native;
     if (N.block_table) (void)hipFree(N.block_table);
     if (N.keys) (void)hipFree(N.keys);
+    if (N.codes) (void)hipFree(N.codes);
     if (N.ids) (void)hipFree(N.ids);
     if (N.keys_b) (void)hipFree(N.keys_b);
     if (N.ids_b) (void)hipFree(N.ids_b);
@@ -1057,8 +1065,8 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
         Scope s(c, "native/hash");
         // one workgroup per CU at most, at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
         const int grid = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
-        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, n,
-                           c->cell_size, N.gx, N.gy, N.blocks_x, N.keys, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl,
+        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n,
+                           c->cell_size, N.gx, N.gy, N.blocks_x, N.keys, N.codes, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl,
                            N.tile_ctl);
         GPE_HIP(c, hipGetLastError());
     }
@@ -1118,6 +1126,9 @@ gpe_status native_configure(gpe_ctx *c)
             *b = nullptr;
             GPE_HIP(c, hipMalloc((void **)b, (c->cap + 16) * sizeof(uint32_t)));
         }
+        if (N.codes) GPE_HIP(c, hipFree(N.codes));
+        N.codes = nullptr;
+        GPE_HIP(c, hipMalloc((void **)&N.codes, (c->cap + 16) * sizeof(uint16_t)));
         N.cap = c->cap;
     }
     const uint64_t tiles = (uint64_t)((N.gx + kTileMain - 1) / kTileMain) * ((N.gy + kTileMain - 1) / kTileMain);
@@ -1210,6 +1221,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.radius = c->radius;
     A.pos_out = pos_out;
     A.sorted_ids = sorted_ids;
+    A.codes = N.codes;
     A.table = N.block_table;
     A.entries = N.table_entries;
     A.blocks_x = N.blocks_x;
