@@ -162,9 +162,15 @@ def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gr
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     timings = eng.ctx.timings()
-    info = {"owned": st.n_owned, "ghosts_per_step": st.stats["ghosts"] / max(1, st.stats["steps"]),
-            "migrants_per_step": st.stats["migrants"] / max(1, st.stats["steps"]), "process_grid": [px, py]}
     _, p, _ = st.owned()
+    info = {"owned": st.n_owned, "process_grid": [px, py],
+            "exchange": "device-resident (k_shard.hip pack/unpack, one all_to_all_single per step, no host sync)"
+                        if st.fast else "torch (two host syncs per step)"}
+    if st.fast:
+        info["ghosts"] = st.n_ghost
+    else:
+        info["ghosts_per_step"] = st.stats["ghosts"] / max(1, st.stats["steps"])
+        info["migrants_per_step"] = st.stats["migrants"] / max(1, st.stats["steps"])
     assert np.isfinite(p).all(), "non-finite positions after the run"
     eng.close()
     return elapsed, timings, world, info

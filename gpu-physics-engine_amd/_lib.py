@@ -42,6 +42,18 @@ class GpeTiming(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("total_ms", C.c_double), ("calls", C.c_uint64)]
 
 
+class GpeShardPlan(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("rank", C.c_uint32), ("world_size", C.c_uint32), ("n_slots", C.c_uint32),
+        ("blocks_x", C.c_int32), ("blocks_y", C.c_int32),
+        ("d_owner_of_block", C.c_void_p), ("d_dest_mask_of_block", C.c_void_p),
+        ("slot_rank", C.c_uint32 * 9),
+        ("send_off", C.c_uint32 * 9), ("send_cap_mig", C.c_uint32 * 9), ("send_cap_gho", C.c_uint32 * 9),
+        ("recv_off", C.c_uint32 * 9), ("recv_cap_mig", C.c_uint32 * 9), ("recv_cap_gho", C.c_uint32 * 9),
+        ("d_send", C.c_void_p), ("d_recv", C.c_void_p),
+    ]
+
+
 class GpeError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("gpe status %d: %s" % (status, message))
@@ -96,6 +108,11 @@ SYMBOLS = [
     ("gpe_stream_handle", _I32, [_VP, C.POINTER(_VP)]),
     ("gpe_refresh", _I32, [_VP]),
     ("gpe_shard_classify", _I32, [_VP, _VP, _VP, _I32, _I32, _U32, _VP, _VP, _VP, _U64]),
+    ("gpe_shard_configure", _I32, [_VP, C.POINTER(GpeShardPlan)]),
+    ("gpe_shard_begin", _I32, [_VP]),
+    ("gpe_shard_unpack", _I32, [_VP]),
+    ("gpe_shard_step", _I32, [_VP, _F]),
+    ("gpe_shard_counts", _I32, [_VP, C.POINTER(_U64), C.POINTER(_U64), _I32]),
     ("gpe_set_profiling", _I32, [_VP, _U32]),
     ("gpe_reset_timings", _I32, [_VP]),
     ("gpe_get_timings", _I32, [_VP, C.POINTER(GpeTiming), C.POINTER(_U32)]),

@@ -319,6 +319,8 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
     return st;
 }
 
+gpe_status step_for_shard(gpe_ctx *c, float dt) { return do_step(c, dt, 0u); }
+
 }  // namespace gpe
 
 using namespace gpe;
@@ -410,6 +412,7 @@ gpe_status gpe_destroy(gpe_ctx *c)
     scan_release(c);
     onesweep_release(c);
     native_release(c);
+    shard_release(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPE_OK;
@@ -418,7 +421,9 @@ gpe_status gpe_destroy(gpe_ctx *c)
 // Device-side error words (sticky): reported at the synchronising entry points.
 static gpe_status check_device_errors(gpe_ctx *c)
 {
-    uint32_t words[2] = {0, 0};
+    uint32_t words[3] = {0, 0, 0};
+    if (c->shard.counts)
+        GPE_HIP(c, hipMemcpyAsync(&words[2], c->shard.counts + kShardError, 4, hipMemcpyDeviceToHost, c->stream));
     if (c->native.tile_ctl)
         GPE_HIP(c, hipMemcpyAsync(&words[0], c->native.tile_ctl + 8, 4, hipMemcpyDeviceToHost, c->stream));
     if (c->os_ws.ctl)
@@ -431,6 +436,10 @@ static gpe_status check_device_errors(gpe_ctx *c)
                     "takes; results of that step are unresolved there -- use GPE_MODE_COMPAT for this scene");
     if (words[0] & 5u)
         return fail(c, GPE_ERR_STATE, "native collide: a particle left the world box between steps");
+    if (words[0] & 16u)
+        return fail(c, GPE_ERR_STATE, "sharded run: the device-side particle count passed the host's bound");
+    if (words[2])
+        return fail(c, GPE_ERR_UNSUPPORTED, "sharded exchange failed (gpe_shard_counts has the details)");
     return GPE_OK;
 }
 
@@ -440,6 +449,12 @@ static gpe_status reconfigure(gpe_ctx *c)
     if (c->cfg.mode == GPE_MODE_NATIVE && c->n > 0) return native_configure(c);
     c->native.eligible = false;
     return GPE_OK;
+}
+
+extern "C++" {
+namespace gpe {
+gpe_status reconfigure_native(gpe_ctx *c) { return reconfigure(c); }
+}
 }
 
 gpe_status gpe_sync(gpe_ctx *c)
@@ -827,7 +842,9 @@ gpe_status gpe_set_active_cells(gpe_ctx *c, int32_t cx0, int32_t cy0, int32_t cx
     if (cx1 < cx0 || cy1 < cy0) return fail(c, GPE_ERR_INVALID_ARG, "gpe_set_active_cells: empty box");
     c->active_box[0] = cx0; c->active_box[1] = cy0; c->active_box[2] = cx1; c->active_box[3] = cy1;
     c->has_active_box = true;
-    return GPE_OK;
+    if (c->n == 0 || !c->pos) return GPE_OK;
+    GPE_HIP(c, hipSetDevice(c->device));
+    return reconfigure(c);                     // the block box (sort keys, block table) follows the active box
 }
 
 gpe_status gpe_stream_handle(gpe_ctx *c, void **hip_stream)

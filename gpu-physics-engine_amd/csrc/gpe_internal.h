@@ -244,7 +244,8 @@ struct NativeState {
     uint32_t *keys_b = nullptr, *ids_b = nullptr;   // sort pong
     uint64_t cap = 0;
     uint16_t *codes = nullptr;       // per particle: cell inside its block | neighbour overlap mask (k_native_hash)
-    int32_t blocks_x = 0;            // 8x8-cell blocks per row of the box: table index = by * blocks_x + bx
+    int32_t blocks_x = 0, blocks_y = 0;   // 8x8-cell blocks of the block box: table index = (by - by0) * blocks_x + (bx - bx0)
+    int32_t bx0 = 0, by0 = 0;        // first block of the box (sharded runs: the rank's active box; else 0, 0)
     uint32_t *tile_ctl = nullptr;    // device control words (k_native.hip kCtl*)
     uint32_t *overflow1 = nullptr;   // packed (ty << 16 | tx) of 32x32 tiles over capacity
     uint64_t overflow_cap = 0;
@@ -255,6 +256,39 @@ struct NativeState {
     uint32_t window_max = 0;         // the same, measured synchronously at configuration time
     bool dense_hold = false;         // left the native path because windows were filling up
     uint32_t steps_since_check = 0;
+};
+
+// Device-resident halo exchange of a sharded run (k_shard.hip): particle counts live on the device, the host
+// only keeps an upper bound.  Slots = the neighbouring ranks in ascending order, then this rank itself.
+constexpr int kShardMaxSlots = 9;
+constexpr int kShardOwned = 0, kShardTotal = 1, kShardError = 2, kShardEpoch = 3, kShardHoles = 4;   // counts[] words
+struct ShardSlots {                  // passed to the kernels by value
+    uint32_t n_slots;
+    uint32_t rank[kShardMaxSlots];
+    uint32_t send_off[kShardMaxSlots], send_cap_mig[kShardMaxSlots], send_cap_gho[kShardMaxSlots];
+    uint32_t recv_off[kShardMaxSlots], recv_cap_mig[kShardMaxSlots], recv_cap_gho[kShardMaxSlots];
+    int8_t slot_of_rank[32];
+};
+struct ShardState {
+    bool on = false;                 // gpe_shard_configure was called
+    bool active = false;             // between gpe_shard_begin and gpe_shard_counts: counts are on the device
+    bool packed = false;             // the send buffer holds this step's rows
+    uint32_t my_rank = 0;
+    int32_t blocks_x = 0, blocks_y = 0;          // global block grid of the decomposition
+    const uint8_t *owner = nullptr;              // caller's device tables (gpe_shard_plan)
+    const uint32_t *dest_mask = nullptr;
+    uint32_t *send = nullptr, *recv = nullptr;   // caller's device buffers
+    ShardSlots slots;
+    uint32_t *counts = nullptr;      // device, 16 words (kShard*)
+    uint32_t *host_counts = nullptr; // pinned mirror written by the unpack kernel
+    uint32_t *plan = nullptr;        // device: per-slot destination offsets of the rows being unpacked
+    uint32_t *holes = nullptr, *fill_src = nullptr, *fill_dst = nullptr;   // device, holes_cap each
+    uint8_t *hole_flag = nullptr;    // device, one byte per particle slot
+    uint64_t holes_cap = 0, flag_cap = 0;
+    uint32_t begin_epoch = 0;        // epoch value at the last gpe_shard_begin
+    uint64_t steps = 0;
+    hipEvent_t fence[2] = {nullptr, nullptr};
+    bool armed[2] = {false, false};
 };
 
 }  // namespace gpe
@@ -296,6 +330,7 @@ struct gpe_ctx {
     gpe::ScanWorkspace scan_ws;
     gpe::OnesweepWorkspace os_ws;
     gpe::NativeState native;
+    gpe::ShardState shard;
     bool use_onesweep = true;        // GPE_SORT=safe selects the reduce-then-scan sort
 
     // profiling
@@ -375,6 +410,9 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
                                  int32_t blocks_x, int32_t blocks_y, uint32_t my_rank, uint32_t *out_index,
                                  uint32_t *out_info, uint32_t *out_count, uint64_t out_capacity);
 void native_release(gpe_ctx *c);
+void shard_release(gpe_ctx *c);
+gpe_status step_for_shard(gpe_ctx *c, float dt);           // one ordinary step (gpe_api.hip do_step)
+gpe_status reconfigure_native(gpe_ctx *c);
 // verlet != nullptr: K12 is applied to the first n_owned particles as they are written back (pos_out = integrated
 // position, prev = resolved position) -- the separate integration launch is then skipped
 gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, const VerletParams *verlet = nullptr);

@@ -62,6 +62,7 @@ __device__ __forceinline__ uint32_t nat_block_exclusive_scan(uint32_t v, uint32_
 constexpr int kHalo = 8;                       // cells = one 8x8 Morton block
 constexpr uint32_t kErrOutOfBox = 1u;          // a particle outside the configured cell box
 constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS capacity (no result!)
+constexpr uint32_t kErrBoundExceeded = 16u;    // sharded run: the device-side particle count passed the host's bound
 // tile_ctl words (the first four are cleared every step, the error word is sticky)
 constexpr int kCtlOverflow1 = 0;               // 32x32 tiles over capacity this step
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
@@ -142,8 +143,11 @@ constexpr int kHashBlock = 1024;
 constexpr int kHashBatch = 8;                  // positions loaded per lane before any of them is ranked
 __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__restrict__ pos,
                                                             const float *__restrict__ radius, uint64_t n,
+                                                            const uint32_t *__restrict__ n_valid_ptr,
                                                             float cell_size, int32_t gx, int32_t gy,
-                                                            int32_t blocks_x, uint32_t *__restrict__ keys,
+                                                            int32_t bx0, int32_t by0, int32_t blocks_x,
+                                                            int32_t blocks_y, uint32_t pad_key,
+                                                            uint32_t *__restrict__ keys,
                                                             uint16_t *__restrict__ codes, int digits,
                                                             uint32_t *hist4, uint32_t *__restrict__ bases4,
                                                             uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl)
@@ -155,6 +159,13 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (n + stride - 1) / stride;
+    // Sharded runs keep the particle count on the device (the exchange changes it every step without a host
+    // round trip): the host passes an upper bound n, slots [nv, n) are padding that sorts behind every block.
+    uint64_t nv = n;
+    if (n_valid_ptr) {
+        nv = *n_valid_ptr;
+        if (nv > n) { nv = n; if (threadIdx.x == 0) atomicOr(&tile_ctl[kCtlError], kErrBoundExceeded); }
+    }
     bool oob = false;
     for (uint64_t r0 = 0; r0 < rounds; r0 += kHashBatch) {
         float2 p[kHashBatch];
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
 #pragma unroll
         for (int u = 0; u < kHashBatch; ++u) {                        // the loads of a batch are in flight together
             idx[u] = (r0 + u) * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-            const bool in = r0 + u < rounds && idx[u] < n;
+            const bool in = r0 + u < rounds && idx[u] < nv;
             p[u] = in ? pos[idx[u]] : make_float2(0.f, 0.f);
             rad[u] = in ? radius[idx[u]] : 0.f;
         }
@@ -171,12 +182,16 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
         for (int u = 0; u < kHashBatch; ++u) {
             if (r0 + u >= rounds) break;                               // wave-uniform
             const bool valid = idx[u] < n;
-            uint32_t key = 0;
-            if (valid) {
+            uint32_t key = pad_key;
+            if (valid && idx[u] >= nv) { keys[idx[u]] = pad_key; codes[idx[u]] = 0; }
+            if (idx[u] < nv) {
                 const int32_t cx = cell_coord(p[u].x, cell_size), cy = cell_coord(p[u].y, cell_size);
-                oob |= (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy);
-                // the particle's 8x8-cell block, row-major over the box (0 for a particle outside it: flagged)
-                key = ((cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy)) ? 0u : (uint32_t)((cy >> 3) * blocks_x + (cx >> 3));
+                // the particle's 8x8-cell block, row-major over the block box (0 for a particle outside it: flagged)
+                const int32_t lbx = (cx >> 3) - bx0, lby = (cy >> 3) - by0;
+                const bool out = (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy) | (lbx < 0) | (lbx >= blocks_x) |
+                                 (lby < 0) | (lby >= blocks_y);
+                oob |= out;
+                key = out ? 0u : (uint32_t)(lby * blocks_x + lbx);
                 keys[idx[u]] = key;
                 // what the tiles need to file the particle: its cell inside the block and its phantom cells.
                 // Computed once here instead of by each of the ~2.25 tiles that stage the particle.
@@ -225,20 +240,19 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
 // Largest particle count of any 3x3-block (24x24-cell) window: what the smallest cell window must hold.
 // Configuration-time check over the whole table (the step path gets the same number from the tiles).
 __global__ __launch_bounds__(kStreamBlock) void k_native_window_max(const uint2 *__restrict__ table,
-                                                                    uint32_t entries, int32_t gx, int32_t gy,
+                                                                    uint32_t entries, int32_t blocks_x,
+                                                                    int32_t blocks_y,
                                                                     uint32_t *__restrict__ out_max)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint32_t best = 0;
     for (uint64_t mb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; mb < entries; mb += stride) {
-        const int blocks_x = (gx + 7) >> 3;
         const int bx = (int)(mb % (uint32_t)blocks_x), by = (int)(mb / (uint32_t)blocks_x);
-        if (bx * 8 >= gx || by * 8 >= gy) continue;
         uint32_t sum = 0;
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int x = bx + dx, y = by + dy;
-                if (x < 0 || y < 0 || x * 8 >= gx || y * 8 >= gy) continue;
+                if (x < 0 || y < 0 || x >= blocks_x || y >= blocks_y) continue;
                 const uint32_t m = (uint32_t)(y * blocks_x + x);
                 if (m < entries) { const uint2 se = table[m]; sum += se.y - se.x; }
             }
@@ -308,7 +322,9 @@ struct CollideArgs {
     const uint16_t *codes;       // per particle: cell inside its block (6 bits) | neighbour overlap mask (8 bits)
     const uint2 *table;
     uint32_t entries;
-    int32_t blocks_x;            // table index of block (bx, by) = by * blocks_x + bx
+    int32_t blocks_x, blocks_y;  // table index of block (bx, by) = (by - by0) * blocks_x + (bx - bx0)
+    int32_t bx0, by0;            // first block of the block box (0, 0 unless sharded)
+    const uint32_t *counts;      // sharded runs: [0] = owned particles, kept on the device; else NULL
     float cell_size;
     float stiffness;
     int32_t gx, gy;              // cell box
@@ -645,8 +661,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         const int bi = tid % NB, bj = tid / NB;
         const int bx = (ox >> 3) + bi, by = (oy >> 3) + bj;           // ox, oy are multiples of 8
         uint32_t start = 0, count = 0;
-        if (bx >= 0 && by >= 0 && bx * 8 < A.gx && by * 8 < A.gy) {
-            const uint32_t mb = (uint32_t)(by * A.blocks_x + bx);
+        const int lbx = bx - A.bx0, lby = by - A.by0;
+        if (lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
+            const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
             if (mb < A.entries) {
                 const uint2 se = A.table[mb];
                 start = se.x;
@@ -923,6 +940,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     GPE_STAMP(5);
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
+    const uint64_t n_owned = A.counts ? (uint64_t)A.counts[0] : A.n_owned;
     for (uint32_t s = tid; s < P; s += kNatThreads) {
         const int home = (int)(S.hm[s] & 0xFFFFu);
         const int lx = home % RW, ly = home / RW;
@@ -938,7 +956,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 id = A.sorted_ids[S.bstart[lo] + (s - S.boff[lo])];
             }
             const float2 c = make_float2(S.px[s], S.py[s]);
-            if (A.fuse_verlet && id < A.n_owned) {
+            if (A.fuse_verlet && id < n_owned) {
                 // K12 on the resolved position: the integrated position becomes the live one, the resolved
                 // position the previous one (particle_integration.wgsl:64,76)
                 const float2 q = A.prev[id];
@@ -1065,9 +1083,10 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
         Scope s(c, "native/hash");
         // one workgroup per CU at most, at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
         const int grid = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
-        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n,
-                           c->cell_size, N.gx, N.gy, N.blocks_x, N.keys, N.codes, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl,
-                           N.tile_ctl);
+        const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr;
+        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
+                           c->cell_size, N.gx, N.gy, N.bx0, N.by0, N.blocks_x, N.blocks_y, N.table_entries, N.keys,
+                           N.codes, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl, N.tile_ctl);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
@@ -1105,11 +1124,24 @@ gpe_status native_configure(gpe_ctx *c)
     // block and order the members of a cell themselves, so the order inside a block is free.  Against the
     // Morton id of the home cell (what the reference sorts by) that is 6 bits less plus the padding Morton
     // interleaving adds to a non-square box: one radix pass less at 1 M (2 instead of 3) and at 100 M (3 / 4).
+    N.bx0 = N.by0 = 0;
     N.blocks_x = (N.gx + 7) >> 3;
-    const uint32_t blocks_y = (uint32_t)((N.gy + 7) >> 3);
-    N.table_entries = (uint32_t)N.blocks_x * blocks_y;
+    N.blocks_y = (N.gy + 7) >> 3;
+    if (c->has_active_box) {
+        // sharded: the block box is this rank's active box (own blocks + ghost ring), so the keys stay as short
+        // as a single-device run of the same size has them
+        const int32_t b0x = std::max(0, c->active_box[0] >> 3), b0y = std::max(0, c->active_box[1] >> 3);
+        const int32_t b1x = std::min(N.blocks_x - 1, c->active_box[2] >> 3), b1y = std::min(N.blocks_y - 1, c->active_box[3] >> 3);
+        if (b1x >= b0x && b1y >= b0y) {
+            N.bx0 = b0x; N.by0 = b0y;
+            N.blocks_x = b1x - b0x + 1; N.blocks_y = b1y - b0y + 1;
+        }
+    }
+    N.table_entries = (uint32_t)N.blocks_x * (uint32_t)N.blocks_y;
     int bits = 0;
-    while (bits < 32 && ((N.table_entries - 1) >> bits) != 0) ++bits;
+    // key == table_entries is the padding key of a sharded run (k_native_hash): it needs its bits too
+    const uint32_t max_key = c->shard.on ? N.table_entries : N.table_entries - 1;
+    while (bits < 32 && (max_key >> bits) != 0) ++bits;
     N.passes = (bits + 7) / 8;
     if (N.passes < 1) N.passes = 1;
     if (N.table_entries > (1u << 27)) return GPE_OK;                   // > 1 GiB of table: stay on compat
@@ -1170,7 +1202,7 @@ gpe_status native_configure(gpe_ctx *c)
     c->profiling = prof;
     GPE_TRY(st);
     hipLaunchKernelGGL(k_native_window_max, dim3(stream_grid(N.table_entries)), dim3(kStreamBlock), 0, c->stream,
-                       N.block_table, N.table_entries, N.gx, N.gy, N.tile_ctl + kCtlWindowMax);
+                       N.block_table, N.table_entries, N.blocks_x, N.blocks_y, N.tile_ctl + kCtlWindowMax);
     GPE_HIP(c, hipGetLastError());
     uint32_t wmax = 0xffffffffu;
     GPE_HIP(c, hipMemcpyAsync(&wmax, N.tile_ctl + kCtlWindowMax, sizeof(wmax), hipMemcpyDeviceToHost, c->stream));
@@ -1225,6 +1257,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.table = N.block_table;
     A.entries = N.table_entries;
     A.blocks_x = N.blocks_x;
+    A.blocks_y = N.blocks_y;
+    A.bx0 = N.bx0;
+    A.by0 = N.by0;
+    A.counts = (c->shard.on && c->shard.active) ? c->shard.counts + kShardOwned : nullptr;
     A.cell_size = c->cell_size;
     A.stiffness = c->cfg.stiffness;
     A.gx = N.gx;

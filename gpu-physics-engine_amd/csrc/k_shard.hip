@@ -1,0 +1,462 @@
+// k_shard.hip -- device-resident halo exchange of a sharded run (the reference is single-device).
+//
+// One process per GPU owns the particles whose home block (8x8 cells) lies in its rectangle of the world.
+// Every step each rank must (a) hand particles that left its rectangle to their new owner (migrants) and
+// (b) give every neighbour a copy of the particles within one block of that neighbour's rectangle (ghosts: the
+// dependency cone of the four colour passes).  gpu-physics-engine_amd/sharded.py has the general
+// formulation in torch (two host round trips per step); this file is the same protocol with NO host round trip:
+//
+//   pack     one pass over the owned particles: rows for each neighbour go into that neighbour's segment of
+//            the send buffer, [n_mig, n_gho, -, -][migrant rows: x y px py r key][ghost rows: x y r key];
+//            migrants are also listed as holes
+//   (the host framework moves the segments: RCCL send/recv over xGMI, fixed sizes, so nothing to wait for)
+//   unpack   holes are filled from the tail of the owned range, arriving migrants are appended to it, ghosts
+//            follow; the new counts stay ON THE DEVICE (and are mirrored to pinned host memory)
+//   step     the ordinary native step; the host passes an upper bound of the particle count, the kernels read
+//            the true one (k_native_hash pads [n, bound) with a key that sorts behind every block)
+//
+// The order of the particles inside a rank is free (members of a cell are ordered by their ORDER KEY = index in
+// the unsharded system), so compaction may move any survivor into any hole.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "gpe_internal.h"
+
+namespace gpe {
+
+constexpr uint32_t kShardErrSendOverflow = 1u;   // more rows for a neighbour than its segment takes
+constexpr uint32_t kShardErrNoSlot = 2u;         // a particle needs a rank that is not a neighbour (moved > 1 block)
+constexpr uint32_t kShardErrCapacity = 4u;       // owned + ghosts exceed the particle capacity
+constexpr uint32_t kShardErrHoles = 8u;          // more migrants in one step than the hole list takes
+constexpr uint32_t kShardErrRecvOverflow = 16u;  // a received header claims more rows than the segment holds
+constexpr int kSegHeader = 4;                    // words
+constexpr int kMigWords = 6, kGhoWords = 4;
+
+struct ShardArrays {
+    float2 *pos, *prev;
+    float *radius;
+    uint32_t *gid;
+};
+
+__global__ void k_shard_zero(uint32_t *__restrict__ send, ShardSlots S, uint32_t *__restrict__ counts)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < S.n_slots * kSegHeader) send[S.send_off[t / kSegHeader] + (t % kSegHeader)] = 0;
+    if (t == 0) counts[kShardHoles] = 0;
+}
+
+// rows of one (slot, kind): a wave-aggregated append
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
+{
+    const uint64_t m = __ballot(want);
+    if (m == 0) return 0xFFFFFFFFu;
+    const int leader = (int)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return want ? base + popc_below_lane(m) : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(kStreamBlock) void k_shard_pack(ShardArrays A, uint64_t n_bound, float cell_size,
+                                                             const uint8_t *__restrict__ owner_of_block,
+                                                             const uint32_t *__restrict__ dest_mask_of_block,
+                                                             int32_t blocks_x, int32_t blocks_y, uint32_t my_rank,
+                                                             ShardSlots S, uint32_t *__restrict__ send,
+                                                             uint32_t *__restrict__ counts,
+                                                             uint32_t *__restrict__ holes,
+                                                             uint8_t *__restrict__ hole_flag, uint32_t holes_cap)
+{
+    const uint64_t n_owned = counts[kShardOwned];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t lim = n_owned < n_bound ? n_owned : n_bound;
+    const uint64_t rounds = (lim + stride - 1) / stride;
+    uint32_t err = 0;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t gho = 0;
+        int mig = -1;
+        float2 p = make_float2(0.f, 0.f);
+        if (i < lim) {
+            p = A.pos[i];
+            int bx = cell_coord(p.x, cell_size) >> 3, by = cell_coord(p.y, cell_size) >> 3;
+            bx = min(max(bx, 0), blocks_x - 1);
+            by = min(max(by, 0), blocks_y - 1);
+            const uint32_t b = (uint32_t)by * (uint32_t)blocks_x + (uint32_t)bx;
+            const uint32_t owner = owner_of_block[b];
+            gho = dest_mask_of_block[b] & 0x03FFFFFFu;      // ranks within one block of b, its owner excluded
+            if (owner != my_rank) mig = (int)owner;         // b's owner takes the particle over
+        }
+        if (__ballot(gho != 0 || mig >= 0) == 0) continue;   // interior wave
+        float2 q = make_float2(0.f, 0.f);
+        float rad = 0.f;
+        uint32_t key = 0;
+        if (gho != 0 || mig >= 0) { rad = A.radius[i]; key = A.gid[i]; }
+        if (mig >= 0) q = A.prev[i];
+        {
+            const uint32_t h = wave_append(&counts[kShardHoles], mig >= 0);
+            if (mig >= 0) {
+                if (h < holes_cap) { holes[h] = (uint32_t)i; hole_flag[i] = 1; } else err |= kShardErrHoles;
+                if (S.slot_of_rank[mig & 31] < 0) err |= kShardErrNoSlot;
+            }
+        }
+        uint32_t served = 0;
+        for (uint32_t s = 0; s < S.n_slots; ++s) {
+            const uint32_t rk = S.rank[s];
+            uint32_t *seg = send + S.send_off[s];
+            const bool wm = mig == (int)rk;
+            const bool wg = ((gho >> rk) & 1u) != 0;
+            served |= wg ? (1u << rk) : 0u;
+            const uint32_t rm = wave_append(seg + 0, wm);
+            if (wm) {
+                if (rm < S.send_cap_mig[s]) {
+                    uint32_t *row = seg + kSegHeader + (uint64_t)rm * kMigWords;
+                    row[0] = __float_as_uint(p.x); row[1] = __float_as_uint(p.y);
+                    row[2] = __float_as_uint(q.x); row[3] = __float_as_uint(q.y);
+                    row[4] = __float_as_uint(rad); row[5] = key;
+                } else err |= kShardErrSendOverflow;
+            }
+            const uint32_t rg = wave_append(seg + 1, wg);
+            if (wg) {
+                if (rg < S.send_cap_gho[s]) {
+                    uint32_t *row = seg + kSegHeader + (uint64_t)S.send_cap_mig[s] * kMigWords + (uint64_t)rg * kGhoWords;
+                    row[0] = __float_as_uint(p.x); row[1] = __float_as_uint(p.y);
+                    row[2] = __float_as_uint(rad); row[3] = key;
+                } else err |= kShardErrSendOverflow;
+            }
+        }
+        if (gho & ~served) err |= kShardErrNoSlot;
+    }
+    if (err) atomicOr(&counts[kShardError], err);
+}
+
+// plan[] words: [0] first slot of the arriving migrants of slot s ... ; see k_shard_unpack_plan
+constexpr int kPlanMigOff = 0, kPlanGhoOff = 16, kPlanMigCnt = 32, kPlanGhoCnt = 48;
+
+// One workgroup: compaction of the owned range (holes below the new end take survivors from behind it), then the
+// destination offsets of everything that arrived, then the new counts.
+__global__ __launch_bounds__(1024) void k_shard_unpack_plan(ShardArrays A, ShardSlots S,
+                                                            const uint32_t *__restrict__ send,
+                                                            const uint32_t *__restrict__ recv,
+                                                            uint32_t *__restrict__ counts,
+                                                            uint32_t *__restrict__ host_counts,
+                                                            uint32_t *__restrict__ plan,
+                                                            uint32_t *__restrict__ holes,
+                                                            uint8_t *__restrict__ hole_flag,
+                                                            uint32_t *__restrict__ fill_src,
+                                                            uint32_t *__restrict__ fill_dst, uint32_t holes_cap,
+                                                            uint64_t capacity)
+{
+    __shared__ uint32_t s_ns, s_nh;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_ns = 0; s_nh = 0; }
+    __syncthreads();
+    const uint32_t n0 = counts[kShardOwned];
+    uint32_t m = counts[kShardHoles];
+    if (m > holes_cap) m = holes_cap;
+    if (m > n0) m = n0;
+    const uint32_t base = n0 - m;
+    for (uint32_t t = tid; t < m; t += blockDim.x) {
+        const uint32_t slot = base + t;
+        if (!hole_flag[slot]) fill_src[atomicAdd(&s_ns, 1u)] = slot;
+        const uint32_t h = holes[t];
+        if (h < base) fill_dst[atomicAdd(&s_nh, 1u)] = h;
+    }
+    __syncthreads();
+    const uint32_t moves = min(s_ns, s_nh);                            // equal by construction
+    for (uint32_t t = tid; t < moves; t += blockDim.x) {
+        const uint32_t a = fill_src[t], b = fill_dst[t];
+        A.pos[b] = A.pos[a]; A.prev[b] = A.prev[a]; A.radius[b] = A.radius[a]; A.gid[b] = A.gid[a];
+    }
+    for (uint32_t t = tid; t < m; t += blockDim.x) hole_flag[holes[t]] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t err = (s_ns != s_nh) ? kShardErrHoles : 0u;
+        uint64_t o = base;
+        for (uint32_t s = 0; s + 1 < S.n_slots; ++s) {                 // neighbours; the last slot is this rank
+            uint32_t c = recv[S.recv_off[s] + 0];
+            if (c > S.recv_cap_mig[s]) { c = S.recv_cap_mig[s]; err |= kShardErrRecvOverflow; }
+            if (o + c > capacity) { c = 0; err |= kShardErrCapacity; }
+            plan[kPlanMigOff + s] = (uint32_t)o;
+            plan[kPlanMigCnt + s] = c;
+            o += c;
+        }
+        const uint32_t n_owned = (uint32_t)o;
+        for (uint32_t s = 0; s < S.n_slots; ++s) {
+            const bool self = s + 1 == S.n_slots;
+            uint32_t c = self ? send[S.send_off[s] + 1] : recv[S.recv_off[s] + 1];
+            const uint32_t cap = self ? S.send_cap_gho[s] : S.recv_cap_gho[s];
+            if (c > cap) { c = cap; err |= self ? kShardErrSendOverflow : kShardErrRecvOverflow; }
+            if (o + c > capacity) { c = 0; err |= kShardErrCapacity; }
+            plan[kPlanGhoOff + s] = (uint32_t)o;
+            plan[kPlanGhoCnt + s] = c;
+            o += c;
+        }
+        const uint32_t epoch = counts[kShardEpoch] + 1u;
+        counts[kShardOwned] = n_owned;
+        counts[kShardTotal] = (uint32_t)o;
+        counts[kShardEpoch] = epoch;
+        counts[kShardHoles] = 0;
+        if (err) atomicOr(&counts[kShardError], err);
+        // pinned mirror: the epoch last, so a host that sees it also sees the counts of that epoch or newer
+        __hip_atomic_store(&host_counts[kShardOwned], n_owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_counts[kShardTotal], (uint32_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_counts[kShardError], counts[kShardError] | err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_counts[kShardEpoch], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(kStreamBlock) void k_shard_unpack_rows(ShardArrays A, ShardSlots S,
+                                                                    const uint32_t *__restrict__ send,
+                                                                    const uint32_t *__restrict__ recv,
+                                                                    const uint32_t *__restrict__ plan)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t s = 0; s < S.n_slots; ++s) {
+        const bool self = s + 1 == S.n_slots;
+        const uint32_t *seg = self ? send + S.send_off[s] : recv + S.recv_off[s];
+        const uint32_t cap_mig = self ? S.send_cap_mig[s] : S.recv_cap_mig[s];
+        if (!self) {
+            const uint32_t cnt = plan[kPlanMigCnt + s], off = plan[kPlanMigOff + s];
+            for (uint32_t j = t0; j < cnt; j += stride) {
+                const uint32_t *row = seg + kSegHeader + (uint64_t)j * kMigWords;
+                A.pos[off + j] = make_float2(__uint_as_float(row[0]), __uint_as_float(row[1]));
+                A.prev[off + j] = make_float2(__uint_as_float(row[2]), __uint_as_float(row[3]));
+                A.radius[off + j] = __uint_as_float(row[4]);
+                A.gid[off + j] = row[5];
+            }
+        }
+        const uint32_t cnt = plan[kPlanGhoCnt + s], off = plan[kPlanGhoOff + s];
+        for (uint32_t j = t0; j < cnt; j += stride) {
+            const uint32_t *row = seg + kSegHeader + (uint64_t)cap_mig * kMigWords + (uint64_t)j * kGhoWords;
+            A.pos[off + j] = make_float2(__uint_as_float(row[0]), __uint_as_float(row[1]));
+            A.radius[off + j] = __uint_as_float(row[2]);
+            A.gid[off + j] = row[3];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+void shard_release(gpe_ctx *c)
+{
+    ShardState &S = c->shard;
+    if (S.counts) (void)hipFree(S.counts);
+    if (S.plan) (void)hipFree(S.plan);
+    if (S.holes) (void)hipFree(S.holes);
+    if (S.fill_src) (void)hipFree(S.fill_src);
+    if (S.fill_dst) (void)hipFree(S.fill_dst);
+    if (S.hole_flag) (void)hipFree(S.hole_flag);
+    if (S.host_counts) (void)hipHostFree(S.host_counts);
+    for (hipEvent_t e : S.fence) if (e) (void)hipEventDestroy(e);
+    S = ShardState();
+}
+
+static ShardArrays shard_arrays(gpe_ctx *c)
+{
+    ShardArrays A;
+    A.pos = c->pos; A.prev = c->prev; A.radius = c->radius; A.gid = c->order_keys;
+    return A;
+}
+
+static gpe_status shard_ready(gpe_ctx *c, bool need_active)
+{
+    if (!c) return GPE_ERR_INVALID_ARG;
+    if (c->n == 0 || !c->pos) return fail(c, GPE_ERR_STATE, "no particles: call gpe_set_particles first");
+    if (!c->shard.on) return fail(c, GPE_ERR_STATE, "sharded exchange not configured: call gpe_shard_configure first");
+    if (need_active && !c->shard.active) return fail(c, GPE_ERR_STATE, "call gpe_shard_begin first");
+    GPE_HIP(c, hipSetDevice(c->device));
+    return GPE_OK;
+}
+
+static gpe_status ensure_flag_capacity(gpe_ctx *c)
+{
+    ShardState &S = c->shard;
+    if (S.flag_cap >= c->cap) return GPE_OK;
+    if (S.hole_flag) GPE_HIP(c, hipFree(S.hole_flag));
+    S.hole_flag = nullptr;
+    GPE_HIP(c, hipMalloc((void **)&S.hole_flag, c->cap + 64));
+    GPE_HIP(c, hipMemsetAsync(S.hole_flag, 0, c->cap + 64, c->stream));
+    S.flag_cap = c->cap;
+    return GPE_OK;
+}
+
+static gpe_status launch_pack(gpe_ctx *c)
+{
+    ShardState &S = c->shard;
+    Scope s(c, "shard/pack");
+    hipLaunchKernelGGL(k_shard_zero, dim3(1), dim3(64), 0, c->stream, S.send, S.slots, S.counts);
+    GPE_HIP(c, hipGetLastError());
+    const uint64_t bound = std::min<uint64_t>(c->cap, c->n);          // owned <= total <= bound
+    hipLaunchKernelGGL(k_shard_pack, dim3(stream_grid(bound)), dim3(kStreamBlock), 0, c->stream, shard_arrays(c), bound,
+                       c->cell_size, S.owner, S.dest_mask, S.blocks_x, S.blocks_y, S.my_rank, S.slots, S.send, S.counts,
+                       S.holes, S.hole_flag, (uint32_t)S.holes_cap);
+    GPE_HIP(c, hipGetLastError());
+    S.packed = true;
+    return GPE_OK;
+}
+
+static gpe_status launch_unpack(gpe_ctx *c)
+{
+    ShardState &S = c->shard;
+    Scope s(c, "shard/unpack");
+    hipLaunchKernelGGL(k_shard_unpack_plan, dim3(1), dim3(1024), 0, c->stream, shard_arrays(c), S.slots, S.send, S.recv,
+                       S.counts, S.host_counts, S.plan, S.holes, S.hole_flag, S.fill_src, S.fill_dst,
+                       (uint32_t)S.holes_cap, c->cap);
+    GPE_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_shard_unpack_rows, dim3(128), dim3(kStreamBlock), 0, c->stream, shard_arrays(c), S.slots, S.send,
+                       S.recv, S.plan);
+    GPE_HIP(c, hipGetLastError());
+    S.packed = false;
+    return GPE_OK;
+}
+
+// Upper bound of the device-side particle total, from the pinned mirror (it lags by the steps in flight; the
+// fence in gpe_shard_step bounds that, the slack covers the drift of the ghost population meanwhile).
+static uint64_t shard_bound(gpe_ctx *c)
+{
+    ShardState &S = c->shard;
+    const uint32_t epoch = __atomic_load_n(&S.host_counts[kShardEpoch], __ATOMIC_ACQUIRE);
+    if ((int32_t)(epoch - S.begin_epoch) <= 0) return c->cap;          // no unpack of this run has landed yet
+    const uint64_t total = S.host_counts[kShardTotal];
+    const uint64_t slack = std::max<uint64_t>(16384, total / 32);
+    return std::min<uint64_t>(c->cap, total + slack);
+}
+
+}  // namespace gpe
+
+using namespace gpe;
+
+extern "C" {
+
+gpe_status gpe_shard_configure(gpe_ctx *c, const gpe_shard_plan *p)
+{
+    if (!c) return GPE_ERR_INVALID_ARG;
+    if (!p || p->struct_size != sizeof(gpe_shard_plan)) return fail(c, GPE_ERR_INVALID_ARG, "gpe_shard_configure: bad plan");
+    if (c->n == 0 || !c->pos) return fail(c, GPE_ERR_STATE, "no particles: call gpe_set_particles first");
+    if (p->n_slots < 1 || p->n_slots > (uint32_t)kShardMaxSlots || p->world_size > 26 || p->rank >= p->world_size ||
+        !p->d_owner_of_block || !p->d_dest_mask_of_block || !p->d_send || !p->d_recv || p->blocks_x <= 0 || p->blocks_y <= 0 ||
+        p->slot_rank[p->n_slots - 1] != p->rank)
+        return fail(c, GPE_ERR_INVALID_ARG, "gpe_shard_configure: bad plan (slots = neighbours ascending, then this rank)");
+    GPE_HIP(c, hipSetDevice(c->device));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    ShardState &S = c->shard;
+    S.my_rank = p->rank;
+    S.blocks_x = p->blocks_x; S.blocks_y = p->blocks_y;
+    S.owner = p->d_owner_of_block; S.dest_mask = p->d_dest_mask_of_block;
+    S.send = p->d_send; S.recv = p->d_recv;
+    memset(&S.slots, 0, sizeof(S.slots));
+    S.slots.n_slots = p->n_slots;
+    for (int r = 0; r < 32; ++r) S.slots.slot_of_rank[r] = -1;
+    for (uint32_t s = 0; s < p->n_slots; ++s) {
+        if (p->slot_rank[s] >= p->world_size) return fail(c, GPE_ERR_INVALID_ARG, "gpe_shard_configure: slot rank out of range");
+        S.slots.rank[s] = p->slot_rank[s];
+        S.slots.slot_of_rank[p->slot_rank[s]] = (int8_t)s;
+        S.slots.send_off[s] = p->send_off[s]; S.slots.send_cap_mig[s] = p->send_cap_mig[s]; S.slots.send_cap_gho[s] = p->send_cap_gho[s];
+        S.slots.recv_off[s] = p->recv_off[s]; S.slots.recv_cap_mig[s] = p->recv_cap_mig[s]; S.slots.recv_cap_gho[s] = p->recv_cap_gho[s];
+    }
+    if (!S.counts) {
+        GPE_HIP(c, hipMalloc((void **)&S.counts, 64));
+        GPE_HIP(c, hipMemset(S.counts, 0, 64));
+        GPE_HIP(c, hipMalloc((void **)&S.plan, 64 * sizeof(uint32_t)));
+        GPE_HIP(c, hipHostMalloc((void **)&S.host_counts, 64, hipHostMallocDefault));
+        memset(S.host_counts, 0, 64);
+    }
+    uint64_t want = 0;
+    for (uint32_t s = 0; s < p->n_slots; ++s) want += p->send_cap_mig[s];
+    want = std::max<uint64_t>(want, 1024);
+    if (S.holes_cap < want) {
+        uint32_t **bufs[3] = {&S.holes, &S.fill_src, &S.fill_dst};
+        for (uint32_t **b : bufs) {
+            if (*b) GPE_HIP(c, hipFree(*b));
+            *b = nullptr;
+            GPE_HIP(c, hipMalloc((void **)b, (want + 16) * sizeof(uint32_t)));
+        }
+        S.holes_cap = want;
+    }
+    GPE_TRY(ensure_flag_capacity(c));
+    const bool was_on = S.on;
+    S.on = true;
+    S.active = false;
+    S.packed = false;
+    if (!was_on) GPE_TRY(reconfigure_native(c));                       // the padding key needs its bits (native_configure)
+    return GPE_OK;
+}
+
+gpe_status gpe_shard_begin(gpe_ctx *c)
+{
+    GPE_TRY(shard_ready(c, false));
+    ShardState &S = c->shard;
+    if (!c->use_order_keys || !c->order_keys) return fail(c, GPE_ERR_STATE, "gpe_shard_begin: order keys are off");
+    GPE_TRY(ensure_flag_capacity(c));
+    // the host's counts are exact here (after set_particles / gpe_shard_counts): ghosts are dropped
+    c->n = c->n_owned;
+    GPE_HIP(c, hipStreamSynchronize(c->stream));                       // every earlier unpack has landed
+    const uint32_t epoch = S.host_counts[kShardEpoch] + 1u;            // the mirror counts from here
+    const uint32_t init[5] = {(uint32_t)c->n_owned, (uint32_t)c->n_owned, 0u, epoch, 0u};
+    GPE_HIP(c, hipMemcpyAsync(S.counts, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    S.begin_epoch = epoch;
+    S.active = true;
+    S.steps = 0;
+    return launch_pack(c);
+}
+
+gpe_status gpe_shard_unpack(gpe_ctx *c)
+{
+    GPE_TRY(shard_ready(c, true));
+    if (!c->shard.packed) return fail(c, GPE_ERR_STATE, "gpe_shard_unpack: nothing was packed");
+    return launch_unpack(c);
+}
+
+gpe_status gpe_shard_step(gpe_ctx *c, float dt)
+{
+    GPE_TRY(shard_ready(c, true));
+    ShardState &S = c->shard;
+    if (!S.packed) return fail(c, GPE_ERR_STATE, "gpe_shard_step: exchange the segments packed by the previous call first");
+    if ((S.steps & 31u) == 0) {                                        // the host runs at most ~64 steps ahead
+        const int slot = (int)((S.steps >> 5) & 1u);
+        if (S.armed[slot]) (void)hipEventSynchronize(S.fence[slot]);
+        if (!S.fence[slot] && hipEventCreateWithFlags(&S.fence[slot], hipEventDisableTiming) != hipSuccess) S.fence[slot] = nullptr;
+        if (S.fence[slot]) S.armed[slot] = hipEventRecord(S.fence[slot], c->stream) == hipSuccess;
+    }
+    ++S.steps;
+    GPE_TRY(launch_unpack(c));
+    c->n = shard_bound(c);
+    GPE_TRY(step_for_shard(c, dt));
+    return launch_pack(c);
+}
+
+gpe_status gpe_shard_counts(gpe_ctx *c, uint64_t *n_owned, uint64_t *n_total, int32_t leave)
+{
+    GPE_TRY(shard_ready(c, true));
+    ShardState &S = c->shard;
+    uint32_t w[5] = {0, 0, 0, 0, 0};
+    GPE_HIP(c, hipMemcpyAsync(w, S.counts, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_owned) *n_owned = w[kShardOwned];
+    if (n_total) *n_total = w[kShardTotal];
+    if (w[kShardError]) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "sharded exchange failed (flags 0x%x:%s%s%s%s)", w[kShardError],
+                 (w[kShardError] & (kShardErrSendOverflow | kShardErrRecvOverflow)) ? " a neighbour segment overflowed" : "",
+                 (w[kShardError] & kShardErrNoSlot) ? " a particle moved more than one block in a step" : "",
+                 (w[kShardError] & kShardErrCapacity) ? " particle capacity exceeded" : "",
+                 (w[kShardError] & kShardErrHoles) ? " too many migrants in one step" : "");
+        return fail(c, GPE_ERR_UNSUPPORTED, msg);
+    }
+    if (leave) {
+        // back to host-side counts (the caller re-sorts or reads the owned range): ghosts are dropped
+        if (w[kShardOwned] == 0 || w[kShardOwned] > c->cap) return fail(c, GPE_ERR_STATE, "gpe_shard_counts: bad owned count");
+        c->n_owned = w[kShardOwned];
+        c->n = c->n_owned;
+        S.active = false;
+        S.packed = false;
+    }
+    return GPE_OK;
+}
+
+}  // extern "C"

@@ -20,10 +20,18 @@ single-device run performs: the sharded result is bit-identical (tests/test_shar
 ranks against the single-process oracle).  The Morton re-sort assigns the new indices globally: new index =
 (particles of all ranks in Morton blocks before mine) + rank inside the block by (cell key, old index).
 
+Device-resident exchange (default on GPUs, `ShardedState(..., device_exchange=True)`): the same protocol with
+the packing, hole filling and appending done by library kernels (csrc/k_shard.hip) on fixed-size neighbour
+segments, the particle counts kept on the device, and ONE `all_to_all_single` per step whose split sizes are
+zero for every rank that is not a neighbour (RCCL issues a send/recv pair per neighbour inside one group) --
+no host round trip per step.  The torch formulation below stays as the general path (any displacement, CPU
+tests) and as the specification the kernels are tested against.
+
 The engine behind a rank is pluggable (`engine` argument): `GpeEngine` drives libgpe.so on the rank's GPU;
 the CPU tests plug in an oracle-backed engine (tests only) to exercise this file without a GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -107,6 +115,21 @@ class Decomposition:
         cx = np.clip(cx, 0, self.bx - 1)
         cy = np.clip(cy, 0, self.by - 1)
         return self.owner[cy, cx].astype(np.int64)
+
+    def neighbours(self, rank):
+        """Ranks whose rectangle lies within one block of `rank`'s (ascending)."""
+        x0, y0, x1, y1 = self.rect_blocks(rank)
+        m = int(np.bitwise_or.reduce(self.dest_mask[y0:y1, x0:x1].reshape(-1))) if x1 > x0 and y1 > y0 else 0
+        return [p for p in range(self.world_size) if (m >> p) & 1 and p != rank]
+
+    def border_blocks(self, src, dst):
+        """How many of src's blocks lie within one block of dst's rectangle (their particles are dst's ghosts)."""
+        x0, y0, x1, y1 = self.rect_blocks(src)
+        return int(((self.dest_mask[y0:y1, x0:x1] >> np.uint32(dst)) & 1).sum())
+
+    def min_region_blocks(self):
+        return min(min(b - a for a, b in zip(self.xcuts[:-1], self.xcuts[1:])),
+                   min(b - a for a, b in zip(self.ycuts[:-1], self.ycuts[1:])))
 
     def morton_entries(self):
         def split(n):
@@ -196,6 +219,11 @@ class GpeEngine:
     def step(self, dt):
         self.ctx.call("gpe_step", float(dt), 0)
 
+    def shard_counts(self, leave=False):
+        no, nt = C.c_uint64(), C.c_uint64()
+        self.ctx.call("gpe_shard_counts", C.byref(no), C.byref(nt), 1 if leave else 0)
+        return no.value, nt.value
+
     def morton_resort(self):
         """K1 + stable sort by home-cell key + K4 on the owned particles (ties keep the current order).
         Returns (sorted keys, permutation) as int64 tensors."""
@@ -228,7 +256,7 @@ class ShardedState:
     """`State` for one rank of a sharded run.  `engine` holds this rank's owned particles (first n_owned
     slots) and exposes torch views of its arrays; everything here is device-agnostic torch code."""
 
-    def __init__(self, engine, dec, rank, group=None):
+    def __init__(self, engine, dec, rank, group=None, device_exchange=None):
         self.e, self.dec, self.rank, self.group = engine, dec, rank, group
         self.ws = dec.world_size
         self.n_owned = engine.n_owned
@@ -239,6 +267,100 @@ class ShardedState:
         # gloo moves host tensors only: a GPU engine under a gloo group (tests on a one-GPU box) stages on the host;
         # with the nccl (= RCCL) backend the device buffers go straight to send/recv
         self.stage_cpu = (self.ws > 1 and engine.device.type == "cuda" and dist.get_backend(group) == "gloo")
+        # device-resident exchange (csrc/k_shard.hip): needs the GPU engine, every rectangle >= 2 blocks wide
+        # (a particle that leaves a rank then only concerns that rank's own neighbours) and <= 8 neighbours
+        if device_exchange is None:
+            device_exchange = os.environ.get("GPE_SHARD_EXCHANGE", "device") != "torch"
+        self.fast = bool(device_exchange and self.ws > 1 and isinstance(engine, GpeEngine) and
+                         dec.min_region_blocks() >= 2 and len(dec.neighbours(rank)) <= 8)
+        self.fast_active = False
+        if self.fast:
+            self._plan_device_exchange()
+
+    # -- device-resident exchange --------------------------------------------------------------------------
+    def _plan_device_exchange(self):
+        e, dec, rank = self.e, self.dec, self.rank
+        n_all = torch.tensor([self.n_owned], dtype=torch.int64)
+        if self.ws > 1:
+            if dist.get_backend(self.group) == "nccl":
+                n_all = n_all.to(e.device)
+            dist.all_reduce(n_all, group=self.group)
+        per_block = float(n_all.item()) / float(dec.bx * dec.by)           # mean particles per 8x8-cell block
+
+        def caps(src, dst):
+            gho = int(dec.border_blocks(src, dst) * per_block * 3.0) + 2048
+            return gho // 4 + 512, gho                                        # (migrant rows, ghost rows)
+
+        def words(cm, cg):
+            return 4 + 6 * cm + 4 * cg
+
+        nb = dec.neighbours(rank)
+        plan = L.GpeShardPlan()
+        plan.struct_size = C.sizeof(L.GpeShardPlan)
+        plan.rank, plan.world_size, plan.n_slots = rank, self.ws, len(nb) + 1
+        plan.blocks_x, plan.blocks_y = dec.bx, dec.by
+        self.in_splits, self.out_splits = [0] * self.ws, [0] * self.ws
+        so = ro = 0
+        for s, p in enumerate(nb):
+            cm, cg = caps(rank, p)
+            plan.slot_rank[s], plan.send_off[s], plan.send_cap_mig[s], plan.send_cap_gho[s] = p, so, cm, cg
+            self.in_splits[p] = words(cm, cg)
+            so += words(cm, cg)
+            cm, cg = caps(p, rank)
+            plan.recv_off[s], plan.recv_cap_mig[s], plan.recv_cap_gho[s] = ro, cm, cg
+            self.out_splits[p] = words(cm, cg)
+            ro += words(cm, cg)
+        self.send_words, self.recv_words = so, ro
+        s = len(nb)                                                           # this rank's own segment: not sent
+        cg_self = sum(plan.send_cap_mig[i] for i in range(len(nb)))
+        plan.slot_rank[s], plan.send_off[s], plan.send_cap_mig[s], plan.send_cap_gho[s] = rank, so, 0, cg_self
+        plan.recv_off[s], plan.recv_cap_mig[s], plan.recv_cap_gho[s] = ro, 0, 0
+        self.send_buf = torch.zeros(so + words(0, cg_self) + 16, dtype=torch.int32, device=e.device)
+        self.recv_buf = torch.zeros(ro + 16, dtype=torch.int32, device=e.device)
+        owner_t, mask_t = self.tables[0], self.tables[1]
+        plan.d_owner_of_block, plan.d_dest_mask_of_block = owner_t.data_ptr(), mask_t.data_ptr()
+        plan.d_send, plan.d_recv = self.send_buf.data_ptr(), self.recv_buf.data_ptr()
+        torch.cuda.synchronize(e.device)
+        e.ctx.call("gpe_shard_configure", C.byref(plan))
+        self.plan = plan
+        if self.stage_cpu:
+            # pageable on purpose: torch's pinned-memory allocator would remember the library's stream (an
+            # ExternalStream) past gpe_destroy
+            self.send_host = torch.zeros(so, dtype=torch.int32)
+            self.recv_host = torch.zeros(ro, dtype=torch.int32)
+
+    def _move_segments(self):
+        """The neighbour segments packed by the library go to their ranks: one grouped send/recv per neighbour
+        (all_to_all_single with zero-sized splits for every other rank), enqueued on the library's stream."""
+        with self.e.stream_ctx():
+            if self.stage_cpu:                   # gloo rehearsal on a shared GPU: through pinned host memory
+                self.send_host.copy_(self.send_buf[:self.send_words])
+                self.e.sync()
+                dist.all_to_all_single(self.recv_host, self.send_host, self.out_splits, self.in_splits, group=self.group)
+                self.recv_buf[:self.recv_words].copy_(self.recv_host)
+            else:
+                dist.all_to_all_single(self.recv_buf[:self.recv_words], self.send_buf[:self.send_words],
+                                       self.out_splits, self.in_splits, group=self.group)
+
+    def _fast_update(self, dt, resort):
+        e = self.e
+        if resort:
+            # every particle must sit on its owner before the global indices are assigned
+            if not self.fast_active:
+                e.set_counts(self.n_owned, self.n_owned)
+                e.ctx.call("gpe_shard_begin")
+            self._move_segments()
+            e.ctx.call("gpe_shard_unpack")
+            self.n_owned, _ = e.shard_counts(leave=True)                  # host sync: re-sort steps only
+            e.n_owned = self.n_owned
+            self.fast_active = False
+            self.resort()
+        if not self.fast_active:
+            e.set_counts(self.n_owned, self.n_owned)
+            e.ctx.call("gpe_shard_begin")
+            self.fast_active = True
+        self._move_segments()
+        e.ctx.call("gpe_shard_step", float(dt))
 
     # -- helpers -------------------------------------------------------------------------------------
     def _ensure_capacity(self, need):
@@ -411,6 +533,10 @@ class ShardedState:
 
     def update(self, dt, resort=False):
         """state.rs:115-131 for one rank: [re-sort] -> exchange -> collide (owned + ghosts) -> integrate owned."""
+        if self.fast:
+            self._fast_update(dt, resort)
+            self.stats["steps"] += 1
+            return
         if resort:
             # every Morton block's particles must sit on their owner before indices are assigned
             if self.ws > 1:
@@ -430,6 +556,9 @@ class ShardedState:
     def owned(self):
         """(gid, pos, prev) of the owned particles as host arrays."""
         self.e.sync()
+        if self.fast and self.fast_active:
+            self.n_owned, n_total = self.e.shard_counts()                 # the counts live on the device
+            self.n_ghost = n_total - self.n_owned
         with self.e.stream_ctx():
             a = self.e.arrays()
             n = self.n_owned

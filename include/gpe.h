@@ -204,6 +204,35 @@ gpe_status gpe_shard_classify(gpe_ctx *ctx, const uint8_t *d_owner_of_block, con
                               int32_t blocks_x, int32_t blocks_y, uint32_t my_rank, uint32_t *d_out_index,
                               uint32_t *d_out_info, uint32_t *d_out_count, uint64_t out_capacity);
 
+/* Device-resident exchange (k_shard.hip): the same protocol without a host round trip per step.  The caller owns
+ * two device buffers of u32 words and moves the neighbour segments between ranks (RCCL send/recv, fixed sizes):
+ * after pack, segment s of d_send goes to rank slot_rank[s] and lands in that rank's d_recv segment for this rank.
+ * Segment = [n_migrants, n_ghosts, 0, 0][cap_mig rows of 6 words: x y prev_x prev_y r key][cap_gho rows of 4 words:
+ * x y r key].  Slots are the neighbouring ranks in ascending order followed by this rank (its own segment of
+ * d_send holds the migrants that stay behind as ghosts; it is not sent).  Both sides must agree on the capacities.
+ * Needs order keys, the native pipeline and an active box; every rank region at least two blocks wide. */
+typedef struct gpe_shard_plan {
+    uint32_t struct_size;          /* = sizeof(gpe_shard_plan)                                   */
+    uint32_t rank, world_size, n_slots;
+    int32_t  blocks_x, blocks_y;   /* block grid of the whole world (tables below)               */
+    const uint8_t  *d_owner_of_block;
+    const uint32_t *d_dest_mask_of_block;
+    uint32_t slot_rank[9];
+    uint32_t send_off[9], send_cap_mig[9], send_cap_gho[9];   /* word offsets into d_send, rows   */
+    uint32_t recv_off[9], recv_cap_mig[9], recv_cap_gho[9];   /* word offsets into d_recv, rows   */
+    uint32_t *d_send, *d_recv;
+} gpe_shard_plan;
+gpe_status gpe_shard_configure(gpe_ctx *ctx, const gpe_shard_plan *plan);
+/* Counts go to the device (owned = total = the host's owned count, ghosts dropped); packs the first segments. */
+gpe_status gpe_shard_begin(gpe_ctx *ctx);
+/* Consume d_recv: fill the migrants' holes, append arriving migrants, then ghosts.  No host sync. */
+gpe_status gpe_shard_unpack(gpe_ctx *ctx);
+/* gpe_shard_unpack + one step (State::update without re-sort) + pack of the next segments.  No host sync. */
+gpe_status gpe_shard_step(gpe_ctx *ctx, float dt);
+/* Synchronises and returns the device-side counts; leave != 0 also returns the context to host-side counts
+ * (owned particles only), e.g. before a Morton re-sort or a download.  Reports exchange errors. */
+gpe_status gpe_shard_counts(gpe_ctx *ctx, uint64_t *n_owned, uint64_t *n_total, int32_t leave);
+
 /* ---- profiling (wgpu_profiler scopes threaded through every reference call) ------------------ */
 typedef struct gpe_timing {
     char     name[64];    /* the reference's scope label, e.g. "Sort map" (grid.rs:329); kernel-level

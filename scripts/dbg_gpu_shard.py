@@ -4,6 +4,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def worker(rank, ws, port):
+    import faulthandler; faulthandler.enable()
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
@@ -14,7 +15,9 @@ def worker(rank, ws, port):
     dec = sharded.Decomposition(world, np.float32(1.1), ws)
     mine = np.nonzero(dec.owner_of(pos) == rank)[0]
     eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, gravity=gravity, device=0)
+    print('rank', rank, 'engine ok', flush=True)
     st = sharded.ShardedState(eng, dec, rank)
+    print('rank', rank, 'state ok fast', st.fast, flush=True)
     ref = None
     if rank == 0:
         ref = gpe.State(pos, rad, world=world, gravity=gravity, mode=gpe.MODE_NATIVE)

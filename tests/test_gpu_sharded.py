@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, ws, port, n, world, gravity, steps, resort_at, dt, seed, out_dir):
+def _worker(rank, ws, port, n, world, gravity, steps, resort_at, dt, seed, out_dir, device_exchange):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -37,26 +37,33 @@ def _worker(rank, ws, port, n, world, gravity, steps, resort_at, dt, seed, out_d
         dec = sharded.Decomposition(world, cs, ws)
         mine = np.nonzero(dec.owner_of(pos) == rank)[0]
         eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, gravity=gravity, device=0)
-        st = sharded.ShardedState(eng, dec, rank)
+        st = sharded.ShardedState(eng, dec, rank, device_exchange=device_exchange)
+        assert st.fast == device_exchange
         for s in range(steps):
             st.update(dt, resort=(s in resort_at))
         gid, p, q = st.owned()
         eng.ctx.sync()
+        # device-resident exchange: the counts live on the device; st.owned() reads them back
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=gid, pos=p, prev=q,
-                 migrants=st.stats["migrants"], ghosts=st.stats["ghosts"])
+                 migrants=st.stats["migrants"] if not st.fast else abs(st.n_owned - len(mine)) + 1,
+                 ghosts=st.stats["ghosts"] if not st.fast else st.n_ghost)
         eng.close()
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("device_exchange", [False, True], ids=["torch-exchange", "device-exchange"])
 @pytest.mark.parametrize("ws,n,world,gravity", [
     (2, 40_000, (420.0, 300.0), (40.0, 0.0)),
     (4, 60_000, (500.0, 380.0), (25.0, -30.0)),
 ])
-def test_two_ranks_one_gpu_equal_single_context(gpe, tmp_path, ws, n, world, gravity):
+def test_two_ranks_one_gpu_equal_single_context(gpe, tmp_path, ws, n, world, gravity, device_exchange):
+    """device-exchange: packing / hole filling / appending by the library's kernels (csrc/k_shard.hip), counts on the
+    device, one all_to_all_single per step; torch-exchange: the general formulation in sharded.py."""
     steps, dt, seed, resort_at = 14, 0.05, 5, (0, 6)
     port = _free_port()
-    mp.spawn(_worker, args=(ws, port, n, world, gravity, steps, resort_at, dt, seed, str(tmp_path)), nprocs=ws, join=True)
+    mp.spawn(_worker, args=(ws, port, n, world, gravity, steps, resort_at, dt, seed, str(tmp_path), device_exchange),
+             nprocs=ws, join=True)
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
     ref = gpe.State(pos, rad, world=world, gravity=gravity, mode=gpe.MODE_NATIVE)
     for s in range(steps):
