@@ -424,10 +424,18 @@ gpe_status gpe_shard_step(gpe_ctx *c, float dt)
         if (S.fence[slot]) S.armed[slot] = hipEventRecord(S.fence[slot], c->stream) == hipSuccess;
     }
     ++S.steps;
-    GPE_TRY(launch_unpack(c));
+    // sampled profiling (gpe_set_profiling(k > 1)): the exchange kernels are bracketed on the same steps as the
+    // step's own kernels (step_for_shard advances the sample counter)
+    const bool sampled = c->profile_every > 1;
+    const bool on = sampled ? (c->profile_step % c->profile_every) == 0 : c->profiling;
+    c->profiling = on;
+    gpe_status st = launch_unpack(c);
     c->n = shard_bound(c);
-    GPE_TRY(step_for_shard(c, dt));
-    return launch_pack(c);
+    if (st == GPE_OK) st = step_for_shard(c, dt);
+    c->profiling = on;
+    if (st == GPE_OK) st = launch_pack(c);
+    if (sampled) c->profiling = true;
+    return st;
 }
 
 gpe_status gpe_shard_counts(gpe_ctx *c, uint64_t *n_owned, uint64_t *n_total, int32_t leave)
