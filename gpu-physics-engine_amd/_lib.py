@@ -42,6 +42,10 @@ class GpeTiming(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("total_ms", C.c_double), ("calls", C.c_uint64)]
 
 
+class GpeTraceEvent(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("start_ms", C.c_double), ("duration_ms", C.c_double)]
+
+
 class GpeShardPlan(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("rank", C.c_uint32), ("world_size", C.c_uint32), ("n_slots", C.c_uint32),
@@ -116,6 +120,7 @@ SYMBOLS = [
     ("gpe_set_profiling", _I32, [_VP, _U32]),
     ("gpe_reset_timings", _I32, [_VP]),
     ("gpe_get_timings", _I32, [_VP, C.POINTER(GpeTiming), C.POINTER(_U32)]),
+    ("gpe_get_trace", _I32, [_VP, C.POINTER(GpeTraceEvent), C.POINTER(_U32)]),
 ]
 
 _lib = None

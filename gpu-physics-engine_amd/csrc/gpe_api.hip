@@ -66,6 +66,8 @@ Scope::~Scope()
     ctx_->pending.push_back(p);
 }
 
+constexpr size_t kTraceCap = 1u << 16;
+
 static void resolve_pending(gpe_ctx *c)
 {
     for (const PendingEvent &p : c->pending) {
@@ -73,6 +75,13 @@ static void resolve_pending(gpe_ctx *c)
         if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
             c->stats[p.stat].total_ms += ms;
             c->stats[p.stat].calls += 1;
+            float t0 = 0.f;
+            if (c->trace_origin && hipEventElapsedTime(&t0, c->trace_origin, p.start) == hipSuccess) {
+                if (c->trace.size() >= kTraceCap) c->trace.erase(c->trace.begin(), c->trace.begin() + kTraceCap / 2);
+                TraceEvent e;
+                e.stat = p.stat; e.start_ms = t0; e.dur_ms = ms;
+                c->trace.push_back(e);
+            }
         }
         c->event_pool.push_back(p.start);
         c->event_pool.push_back(p.stop);
@@ -407,6 +416,7 @@ gpe_status gpe_destroy(gpe_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     resolve_pending(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->trace_origin) (void)hipEventDestroy(c->trace_origin);
     free_particle_buffers(c);
     sort_release(c);
     scan_release(c);
@@ -875,12 +885,20 @@ gpe_status gpe_shard_classify(gpe_ctx *c, const uint8_t *d_owner_of_block, const
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------------
+static gpe_status mark_trace_origin(gpe_ctx *c)
+{
+    if (!c->trace_origin) GPE_HIP(c, hipEventCreate(&c->trace_origin));
+    GPE_HIP(c, hipEventRecord(c->trace_origin, c->stream));
+    return GPE_OK;
+}
+
 gpe_status gpe_set_profiling(gpe_ctx *c, uint32_t on)
 {
     if (!c) return GPE_ERR_INVALID_ARG;
     c->profiling = on != 0;
     c->profile_every = on;
     c->profile_step = 0;
+    if (on && !c->trace_origin) GPE_TRY(mark_trace_origin(c));
     return GPE_OK;
 }
 
@@ -890,6 +908,27 @@ gpe_status gpe_reset_timings(gpe_ctx *c)
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     resolve_pending(c);
     c->stats.clear();
+    c->trace.clear();
+    return mark_trace_origin(c);
+}
+
+gpe_status gpe_get_trace(gpe_ctx *c, gpe_trace_event *out, uint32_t *count)
+{
+    if (!c || !count) return GPE_ERR_INVALID_ARG;
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    resolve_pending(c);
+    const uint32_t avail = (uint32_t)c->trace.size();
+    if (out) {
+        const uint32_t m = std::min(avail, *count);
+        for (uint32_t i = 0; i < m; ++i) {
+            const TraceEvent &e = c->trace[avail - m + i];               // the newest m, oldest first
+            memset(&out[i], 0, sizeof(gpe_trace_event));
+            strncpy(out[i].name, c->stats[e.stat].name.c_str(), sizeof(out[i].name) - 1);
+            out[i].start_ms = e.start_ms;
+            out[i].duration_ms = e.dur_ms;
+        }
+    }
+    *count = avail;
     return GPE_OK;
 }
 

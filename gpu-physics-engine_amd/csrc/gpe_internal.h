@@ -209,6 +209,10 @@ struct PendingEvent {
     int stat;
     hipEvent_t start, stop;
 };
+struct TraceEvent {                  // one resolved scope instance (gpe_get_trace)
+    int stat;
+    double start_ms, dur_ms;         // start relative to the trace origin (gpe_set_profiling / gpe_reset_timings)
+};
 
 struct ScanWorkspace {           // reduce-then-scan tile sums, one array per recursion level
     std::vector<uint32_t *> level;
@@ -230,6 +234,7 @@ struct OnesweepWorkspace {
     uint32_t *bases4 = nullptr;      // 4 x 256 exclusive digit bases
     uint32_t *ctl = nullptr;         // [0..3] tile tickets per pass, [4] error word
     uint32_t epoch = 0;
+    bool hist_clean = false;         // hist4 (all copies) is zero: the native step keeps it so between steps
 };
 
 // Native (N-key sort + LDS cell windows) pipeline state
@@ -254,6 +259,8 @@ struct NativeState {
     bool force = false;              // GPE_NATIVE_FORCE=1 (tests): no hand-over to the compat kernels
     uint32_t *host_stat = nullptr;   // pinned: [0] last reported max 24x24-cell window population
     uint32_t window_max = 0;         // the same, measured synchronously at configuration time
+    hipStream_t stream2 = nullptr;   // the launch for over-capacity tiles runs beside the dense launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dense_hold = false;         // left the native path because windows were filling up
     uint32_t steps_since_check = 0;
 };
@@ -340,6 +347,8 @@ struct gpe_ctx {
     std::vector<gpe::ScopeStat> stats;
     std::vector<gpe::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
+    hipEvent_t trace_origin = nullptr;            // recorded when profiling is switched on / timings are reset
+    std::vector<gpe::TraceEvent> trace;           // the last kTraceCap resolved scopes, oldest first
 };
 
 namespace gpe {

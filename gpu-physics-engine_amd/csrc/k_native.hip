@@ -78,26 +78,6 @@ constexpr int kTileSmall = 8, kCapSmall = 2048;
 constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows above this population
 
 // ---------------------------------------------------------------------------------------------------
-// clear: one launch zeroes everything a step accumulates into (block table, digit histograms, per-step
-// control words) and hands the previous step's window statistic to the host (pinned memory).
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kStreamBlock) void k_native_clear(uint4 *__restrict__ table2, uint64_t table_pairs,
-                                                               uint32_t *__restrict__ hist4,
-                                                               uint32_t *__restrict__ tile_ctl,
-                                                               uint32_t *__restrict__ host_stat)
-{
-    if (blockIdx.x == 0) {
-        for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kStreamBlock) hist4[i] = 0;
-        if (threadIdx.x == 0 && host_stat) host_stat[0] = tile_ctl[kCtlWindowMax];
-        __syncthreads();
-        if (threadIdx.x < kCtlPerStepWords) tile_ctl[threadIdx.x] = 0;
-    }
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += stride)
-        table2[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-// ---------------------------------------------------------------------------------------------------
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
 // (home_cell_ids.wgsl:24-31 computes the Morton id of the home cell; the key kept here is the row-major index
 // of its 8x8-cell block; the particle id is implicit in the first pass.)
@@ -150,12 +130,24 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
                                                             uint32_t *__restrict__ keys,
                                                             uint16_t *__restrict__ codes, int digits,
                                                             uint32_t *hist4, uint32_t *__restrict__ bases4,
-                                                            uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl)
+                                                            uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl,
+                                                            uint4 *__restrict__ table2, uint64_t table_pairs,
+                                                            uint32_t *__restrict__ host_stat)
 {
     __shared__ uint32_t s_hist[4 * 256];
     __shared__ uint32_t s_w[kHashBlock / 64];
     __shared__ uint32_t s_last;
     s_hist[threadIdx.x] = 0;
+    // What a step accumulates into is reset here instead of by a launch of its own (a launch costs ~6 us, 5 % of
+    // the step at 1 M particles): the block table (filled two kernels later), and -- workgroup 0 -- the per-step
+    // control words, after handing the previous step's window statistic to the host (pinned memory).  The digit
+    // histograms are zeroed by the previous step's table kernel, the done-ticket by the workgroup that takes it last.
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
+        table2[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords && threadIdx.x != kCtlHashDone) {
+        if (threadIdx.x == kCtlWindowMax && host_stat) host_stat[0] = tile_ctl[kCtlWindowMax];
+        tile_ctl[threadIdx.x] = 0;
+    }
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (n + stride - 1) / stride;
@@ -235,6 +227,7 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
     for (int i = w & ~3; i < w; ++i) base += s_w[i];
     bases4[threadIdx.x] = base + inc - v;
     if (threadIdx.x < 8) os_ctl[threadIdx.x] = 0;                      // tile tickets + error word
+    if (threadIdx.x == 0) tile_ctl[kCtlHashDone] = 0;                  // every workgroup has taken its ticket
 }
 
 // Largest particle count of any 3x3-block (24x24-cell) window: what the smallest cell window must hold.
@@ -283,8 +276,11 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_check_box(const float2 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kStreamBlock) void k_native_block_table(const uint32_t *__restrict__ sorted_keys,
                                                                      uint64_t n, uint2 *__restrict__ table,
-                                                                     uint32_t entries)
+                                                                     uint32_t entries, uint32_t *__restrict__ hist4)
 {
+    // the digit histograms are dead once the radix passes have run: zero them for the next step's hash
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)kHistCopies * 4u * 256u; i += gridDim.x * blockDim.x)
+        hist4[i] = 0;
     // four consecutive keys per lane (one 16-byte load) + the two neighbours of the quad
     const uint64_t quads = (n + 3) / 4;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -334,6 +330,7 @@ struct CollideArgs {
     uint32_t *tile_ctl;          // kCtl* words
     uint32_t *overflow1;         // packed (ty << 16 | tx) of over-capacity 32x32 tiles
     uint32_t overflow1_cap;
+    uint32_t classified;         // k_tile_classify fills the list (two-stream mode); else the dense tiles do
     // spill arena (global memory) for the particle arrays of such tiles
     float *arena_px, *arena_py, *arena_rad;
     uint32_t *arena_id, *arena_hm, *arena_mem;   // arena_mem holds 4 entries per particle
@@ -493,15 +490,55 @@ __device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint3
     }
 }
 
-// The reference's pair resolution (collision_solver.wgsl:66-118), on LDS-resident positions.
-// Bit-exact restatements used to shorten the dependent chain of the sequential pair loop:
-//  * the next partner's position is fetched while the current pair is computed: within one `a` loop
-//    every pair touches a different partner, so that position cannot change in between;
-//  * inv_mass_1 (:103) is the same value for every pair of `a` and is computed once;
-//  * r1 == r2 (and 1/r finite, non-zero): inv1 == inv2 and inv1 + inv1 == 2*inv1 exactly, so both
-//    weights (:107-108) are exactly 0.5 -- the three divisions are skipped, not approximated;
-//  * q = vx*vx + vy*vy > 1.000001 * rs*rs implies rs*rs <= distance*distance (distance = sqrt(q) correctly
-//    rounded, so distance*distance >= q * (1 - 2^-22)): no collision (:95), and the square root is skipped.
+// One pair of the reference's response (collision_solver.wgsl:91-111), shared by the one-lane-per-cell and the
+// lane-group resolution.  One wave-uniform early-out (no lane of the wave can collide), then straight-line code
+// whose result a lane keeps or not by select.  Bit-exact shortcuts:
+//  * r1 == r2 (and 1/r finite, non-zero): inv1 == inv2 and inv1 + inv1 == 2 inv1 exactly, so both weights
+//    (:107-108) are exactly 0.5 -- the three divisions are skipped, not approximated.
+//  * q = vx*vx + vy*vy > 1.000001 rs^2 implies rs^2 <= distance^2 (distance = sqrt(q) correctly rounded, so
+//    distance^2 >= q (1 - 2^-22)): no collision (:95); q < 9.9e-9 implies distance < 0.0001 (:95; 0.0001f squared
+//    is 9.99999995e-9): no collision either.  Neither needs the square root.
+// sqrtf and '/' are hipcc's correctly rounded sequences.  (Measured and dropped: the same sequences without their
+// denormal / special-case steps and with one shared reciprocal for the two divisions -- 11 wave instructions
+// fewer per pair, same bits, 2 % SLOWER: the passes are bound by the dependent chain, not by issue slots.)
+// Returns the wave-uniform "some lane collided"; (p1, p2) are updated in place for lanes that collide.
+__device__ __forceinline__ bool pair_response(const bool active, float &p1x, float &p1y, float &p2x, float &p2y,
+                                              const float r1, const float r2, const bool r1_plain,
+                                              const float stiffness, bool &hit)
+{
+    const float vx = p1x - p2x, vy = p1y - p2y;                       // :91 (live positions, :86)
+    const float q = vx * vx + vy * vy;
+    const float radius_sum = r1 + r2;                                 // :61
+    const float rs2 = radius_sum * radius_sum;
+    const bool cand = active && q <= rs2 * 1.000001f && q >= 9.9e-9f;
+    hit = false;
+    if (__ballot(cand) == 0) return false;                            // wave-uniform
+    const float distance = sqrtf(q);                                  // :93
+    hit = cand && rs2 > distance * distance && distance > 0.0001f;    // :95
+    const float depth = radius_sum - distance;                        // :97
+    const float cx = ((vx / distance) * depth) * stiffness;           // :98,101
+    const float cy = ((vy / distance) * depth) * stiffness;
+    float w1 = 0.5f, w2 = 0.5f;                                       // == inv1 / (inv1 + inv1), exactly
+    const bool general = hit && !(r1 == r2 && r1_plain);
+    if (__ballot(general) != 0) {                                     // wave-uniform: unequal radii somewhere
+        if (general) {
+            const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;           // :103,104
+            w1 = inv1 / (inv1 + inv2);                                // :107
+            w2 = inv2 / (inv1 + inv2);                                // :108
+        }
+    }
+    const float n1x = p1x + cx * w1, n1y = p1y + cy * w1;             // :110
+    const float n2x = p2x - cx * w2, n2y = p2y - cy * w2;             // :111
+    p1x = hit ? n1x : p1x; p1y = hit ? n1y : p1y;
+    p2x = hit ? n2x : p2x; p2y = hit ? n2y : p2y;
+    return __ballot(hit) != 0;
+}
+
+// The reference's pair resolution (collision_solver.wgsl:66-118), on LDS-resident positions: one lane walks the
+// pairs (a, b), a < b, of its cell.  Bit-exact restatements that shorten the dependent chain:
+//  * the next partner's position is fetched while the current pair is computed: within one `a` loop every pair
+//    touches a different partner, so that position cannot change in between;
+//  * see pair_response for the arithmetic.
 template <class L>
 __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint32_t e, const float stiffness)
 {
@@ -511,36 +548,16 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
         float p1x = S.px[a], p1y = S.py[a];
         const float r1 = S.rad[a];
         float nx = S.px[nb], ny = S.py[nb], nr = S.rad[nb];
-        const float inv1 = 1.0f / r1;                                 // :103
         const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
         bool dirty = false;
         for (uint32_t ib = ia + 1; ib < e; ++ib) {                    // :77
             const uint32_t bb = nb;
-            const float p2x = nx, p2y = ny, r2 = nr;                  // :86 live position
+            float p2x = nx, p2y = ny;                                 // :86 live position
+            const float r2 = nr;
             if (ib + 1 < e) { nb = S.mem[ib + 1]; nx = S.px[nb]; ny = S.py[nb]; nr = S.rad[nb]; }
-            const float vx = p1x - p2x, vy = p1y - p2y;               // :91
-            const float q = vx * vx + vy * vy;
-            const float radius_sum = r1 + r2;                         // :61
-            const float rs2 = radius_sum * radius_sum;
-            if (q > rs2 * 1.000001f) continue;                        // no collision, see above: sqrt skipped
-            const float distance = sqrtf(q);                          // :93
-            if (rs2 > distance * distance && distance > 0.0001f) {    // :95
-                const float depth = radius_sum - distance;            // :97
-                const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
-                const float cy = ((vy / distance) * depth) * stiffness;
-                float w1, w2;
-                if (r1 == r2 && r1_plain) {
-                    w1 = 0.5f; w2 = 0.5f;                             // == inv1 / (inv1 + inv1), exactly
-                } else {
-                    const float inv2 = 1.0f / r2;                     // :104
-                    w1 = inv1 / (inv1 + inv2);                        // :107
-                    w2 = inv2 / (inv1 + inv2);                        // :108
-                }
-                p1x = p1x + cx * w1;                                  // :110
-                p1y = p1y + cy * w1;
-                S.px[bb] = p2x - cx * w2;                             // :111
-                S.py[bb] = p2y - cy * w2;
-                dirty = true;
+            bool hit;
+            if (pair_response(true, p1x, p1y, p2x, p2y, r1, r2, r1_plain, stiffness, hit)) {
+                if (hit) { S.px[bb] = p2x; S.py[bb] = p2y; dirty = true; }
             }
         }
         if (dirty) { S.px[a] = p1x; S.py[a] = p1y; }
@@ -607,32 +624,13 @@ __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint
         qb = -1;
         if (ib == a) {                                                // the lane's own particle has arrived
             p1x = ix; p1y = iy;
-        } else if (ib > a && has) {                                   // pair (a, ib), step t == a + ib - 1
-            const float r2 = ir;
-            const float vx = p1x - ix, vy = p1y - iy;                 // :91 (live positions, :86)
-            const float q = vx * vx + vy * vy;
-            const float radius_sum = r1 + r2;                         // :61
-            const float rs2 = radius_sum * radius_sum;
-            if (q <= rs2 * 1.000001f) {                               // else: no collision (see resolve_cell)
-                const float distance = sqrtf(q);                      // :93
-                if (rs2 > distance * distance && distance > 0.0001f) {    // :95
-                    const float depth = radius_sum - distance;        // :97
-                    const float cx = ((vx / distance) * depth) * stiffness;   // :98,101
-                    const float cy = ((vy / distance) * depth) * stiffness;
-                    float w1, w2;
-                    if (r1 == r2 && r1_plain) {
-                        w1 = 0.5f; w2 = 0.5f;                         // == inv1 / (inv1 + inv1), exactly
-                    } else {
-                        const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;   // :103,104
-                        w1 = inv1 / (inv1 + inv2);                    // :107
-                        w2 = inv2 / (inv1 + inv2);                    // :108
-                    }
-                    p1x = p1x + cx * w1;                              // :110
-                    p1y = p1y + cy * w1;
-                    ix = ix - cx * w2;                                // :111
-                    iy = iy - cy * w2;
-                }
-            }
+        }
+        // pair (a, ib), step t == a + ib - 1: every lane runs the straight-line response, lanes without a pair
+        // this step are masked out by `active`
+        const bool pairing = ib > a && has;
+        bool hit;
+        (void)pair_response(pairing, p1x, p1y, ix, iy, r1, ir, r1_plain, stiffness, hit);
+        if (pairing) {
             qx = ix; qy = iy; qr = ir; qb = ib;
         }
     }
@@ -986,8 +984,35 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
     const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
-    if (!process_tile(S, A, tx, ty)) {
+    // a tile whose 48x48-cell region exceeds the window's capacity returns at once and is listed for
+    // k_collide_overflow (unless k_tile_classify has listed it already from the same block table: two-stream mode)
+    if (!process_tile(S, A, tx, ty) && !A.classified) {
         if (threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
+            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+            else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
+        }
+    }
+}
+
+// Lists the 32x32 tiles whose region holds more particles than the main window stages (the test process_tile
+// makes on the same table), so that the dense launch and the launch for these tiles do not wait for each other.
+__global__ __launch_bounds__(kStreamBlock) void k_tile_classify(CollideArgs A)
+{
+    constexpr int NB = (kTileMain + 2 * kHalo) / 8;
+    const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
+        const int b0x = ((tx * kTileMain - kHalo) >> 3) - A.bx0, b0y = ((ty * kTileMain - kHalo) >> 3) - A.by0;
+        uint32_t P = 0;
+        for (int bj = 0; bj < NB; ++bj)
+            for (int bi = 0; bi < NB; ++bi) {
+                const int lbx = b0x + bi, lby = b0y + bj;
+                if (lbx < 0 || lby < 0 || lbx >= A.blocks_x || lby >= A.blocks_y) continue;
+                const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
+                if (mb < A.entries) { const uint2 se = A.table[mb]; P += se.y - se.x; }
+            }
+        if (P > (uint32_t)kCapMain) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
             if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
             else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
@@ -1064,6 +1089,9 @@ void native_release(gpe_ctx *c)
     if (N.overflow1) (void)hipFree(N.overflow1);
     if (N.arena) (void)hipFree(N.arena);
     if (N.host_stat) (void)hipHostFree(N.host_stat);
+    if (N.ev_fork) (void)hipEventDestroy(N.ev_fork);
+    if (N.ev_join) (void)hipEventDestroy(N.ev_join);
+    if (N.stream2) (void)hipStreamDestroy(N.stream2);
     N = NativeState();
 }
 
@@ -1072,21 +1100,20 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
 {
     NativeState &N = c->native;
     const uint64_t n = c->n;
-    {
-        Scope s(c, "native/clear");
-        const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;    // the table is allocated in 16-byte units
-        hipLaunchKernelGGL(k_native_clear, dim3(stream_grid(pairs)), dim3(kStreamBlock), 0, c->stream,
-                           (uint4 *)N.block_table, pairs, c->os_ws.hist4, N.tile_ctl, N.host_stat);
-        GPE_HIP(c, hipGetLastError());
+    if (!c->os_ws.hist_clean) {                                        // another sort used the histograms since
+        GPE_HIP(c, hipMemsetAsync(c->os_ws.hist4, 0, (size_t)kHistCopies * 4 * 256 * sizeof(uint32_t), c->stream));
+        c->os_ws.hist_clean = true;
     }
     {
         Scope s(c, "native/hash");
+        const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;    // the table is allocated in 16-byte units
         // one workgroup per CU at most, at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
         const int grid = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
         const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr;
         hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
                            c->cell_size, N.gx, N.gy, N.bx0, N.by0, N.blocks_x, N.blocks_y, N.table_entries, N.keys,
-                           N.codes, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl, N.tile_ctl);
+                           N.codes, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl, N.tile_ctl,
+                           (uint4 *)N.block_table, pairs, N.host_stat);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
@@ -1097,7 +1124,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     {
         Scope s(c, "native/table");
         hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid((n + 3) / 4)), dim3(kStreamBlock), 0, c->stream, sk, n,
-                           N.block_table, N.table_entries);
+                           N.block_table, N.table_entries, c->os_ws.hist4);
         GPE_HIP(c, hipGetLastError());
     }
     *sorted_ids = sv;
@@ -1300,25 +1327,47 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         (void)hipMemset(g_stamps, 0, 32 * 8);
     }
 #endif
+    int32_t cx0 = 0, cy0 = 0, cx1 = N.gx - 1, cy1 = N.gy - 1;
+    if (c->has_active_box) {                                           // sharded: only this rank's cells
+        cx0 = std::max(cx0, c->active_box[0]); cy0 = std::max(cy0, c->active_box[1]);
+        cx1 = std::min(cx1, c->active_box[2]); cy1 = std::min(cy1, c->active_box[3]);
+        if (cx1 < cx0 || cy1 < cy0) { cx1 = cx0; cy1 = cy0; }
+    }
+    A.tile_x0 = cx0 / kTileMain;
+    A.tile_y0 = cy0 / kTileMain;
+    A.tiles_x = cx1 / kTileMain - A.tile_x0 + 1;
+    A.tiles_y = cy1 / kTileMain - A.tile_y0 + 1;
+    const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
+    // Tiles whose 48x48-cell region exceeds the LDS capacity are redone as 16x16 tiles, 8x8 tiles, spill arena by a
+    // second launch.  GPE_OVERFLOW_STREAM=1 runs it on a second stream BESIDE the dense launch (both read the
+    // step-start positions and write disjoint particles; a classify kernel lists the tiles from the block table):
+    // that pays when many tiles overflow (clustered scenes); the stream fork/join costs ~8 us per step, more
+    // than the empty launch it hides, so the default is one stream.
+    static const bool two_streams = [] { const char *e = getenv("GPE_OVERFLOW_STREAM"); return e && e[0] == '1'; }();
+    A.classified = two_streams ? 1u : 0u;
+    const uint32_t grid = ((total + 7u) / 8u) * 8u;
+    if (two_streams) {
+        if (!N.stream2) {
+            GPE_HIP(c, hipStreamCreateWithFlags(&N.stream2, hipStreamNonBlocking));
+            GPE_HIP(c, hipEventCreateWithFlags(&N.ev_fork, hipEventDisableTiming));
+            GPE_HIP(c, hipEventCreateWithFlags(&N.ev_join, hipEventDisableTiming));
+        }
+        GPE_HIP(c, hipEventRecord(N.ev_fork, c->stream));
+        GPE_HIP(c, hipStreamWaitEvent(N.stream2, N.ev_fork, 0));
+        hipLaunchKernelGGL(k_tile_classify, dim3(stream_grid(total)), dim3(kStreamBlock), 0, N.stream2, A);
+        GPE_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(k_collide_overflow, dim3(512), dim3(kNatThreads), 0, N.stream2, A);
+        GPE_HIP(c, hipGetLastError());
+        GPE_HIP(c, hipEventRecord(N.ev_join, N.stream2));
+    }
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
-        int32_t cx0 = 0, cy0 = 0, cx1 = N.gx - 1, cy1 = N.gy - 1;
-        if (c->has_active_box) {                                       // sharded: only this rank's cells
-            cx0 = std::max(cx0, c->active_box[0]); cy0 = std::max(cy0, c->active_box[1]);
-            cx1 = std::min(cx1, c->active_box[2]); cy1 = std::min(cy1, c->active_box[3]);
-            if (cx1 < cx0 || cy1 < cy0) { cx1 = cx0; cy1 = cy0; }
-        }
-        A.tile_x0 = cx0 / kTileMain;
-        A.tile_y0 = cy0 / kTileMain;
-        A.tiles_x = cx1 / kTileMain - A.tile_x0 + 1;
-        A.tiles_y = cy1 / kTileMain - A.tile_y0 + 1;
-        const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
-        const uint32_t grid = ((total + 7u) / 8u) * 8u;
         hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
-    {
-        // tiles whose 48x48-cell region exceeded the LDS capacity: 16x16 tiles, 8x8 tiles, spill arena
+    if (two_streams) {
+        GPE_HIP(c, hipStreamWaitEvent(c->stream, N.ev_join, 0));
+    } else {
         Scope s(c, "native/collide-dense-regions");
         hipLaunchKernelGGL(k_collide_overflow, dim3(512), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());

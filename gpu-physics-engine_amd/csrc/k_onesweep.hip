@@ -405,6 +405,7 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
     OnesweepWorkspace &ws = c->os_ws;
     const uint64_t tiles = os_tiles(n);
     if (!hist_ready) {
+        ws.hist_clean = false;
         Scope s(c, "sort/hist");
         GPE_TRY(onesweep_zero_hist(c));
         hipLaunchKernelGGL(k_os_hist4, dim3(stream_grid(n, kStreamBlock)), dim3(kStreamBlock), 0, c->stream, keys, n,

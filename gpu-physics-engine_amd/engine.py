@@ -82,6 +82,25 @@ class Context:
         self.call("gpe_get_timings", arr, C.byref(cnt2))
         return {arr[i].name.decode(): (arr[i].total_ms, arr[i].calls) for i in range(min(cnt.value, cnt2.value))}
 
+    def trace(self):
+        """[(scope name, start ms, duration ms)] of the recorded scope instances, oldest first (gpe_get_trace)."""
+        cnt = C.c_uint32(0)
+        self.call("gpe_get_trace", None, C.byref(cnt))
+        arr = (L.GpeTraceEvent * max(1, cnt.value))()
+        cnt2 = C.c_uint32(cnt.value)
+        self.call("gpe_get_trace", arr, C.byref(cnt2))
+        return [(arr[i].name.decode(), arr[i].start_ms, arr[i].duration_ms) for i in range(min(cnt.value, cnt2.value))]
+
+    def write_chrome_trace(self, path):
+        """The reference's `benchmark.json` (state.rs:108-112): one complete event ("ph": "X", microseconds) per
+        recorded scope, loadable by chrome://tracing / Perfetto."""
+        import json
+        events = [{"name": n, "cat": "gpu", "ph": "X", "ts": t0 * 1e3, "dur": d * 1e3, "pid": 0, "tid": 0}
+                  for n, t0, d in self.trace()]
+        with open(path, "w") as f:
+            json.dump({"traceEvents": events, "displayTimeUnit": "ms"}, f)
+        return len(events)
+
     def reset_timings(self):
         self.call("gpe_reset_timings")
 
@@ -305,6 +324,7 @@ class State:
 
     def __init__(self, positions, radii, world=(3048.0, 1048.0), gravity=(0.0, 0.0), mode=L.MODE_COMPAT,
                  prev=None, device=-1, profiling=False):
+        self.world, self.gravity, self.mode = tuple(map(float, world)), tuple(map(float, gravity)), mode
         self.ctx = Context(world=world, gravity=gravity, mode=mode, device=device, profiling=profiling)
         self.particles = ParticleSystem.new_from_buffers(self.ctx, positions, radii, prev=prev)
         self.grid = Grid(self.ctx, self.particles)
@@ -326,6 +346,26 @@ class State:
 
     def previous_positions(self):
         return self.ctx.download(L.PREV, np.float32, (-1, 2))
+
+    def radii(self):
+        return self.ctx.download(L.RADIUS, np.float32)
+
+    # Checkpoint / restore (the reference's only state dump is download_particle_buffers,
+    # particle_system.rs:258-265): the three arrays the step evolves plus the constants a step depends on.
+    def save(self, path):
+        """Binary snapshot (numpy .npz, no pickle): positions, previous positions, radii, world, gravity."""
+        np.savez(path, format=np.array([1], np.int32), pos=self.positions(), prev=self.previous_positions(),
+                 radius=self.radii(), world=np.array(self.world, np.float32), gravity=np.array(self.gravity, np.float32))
+
+    @classmethod
+    def load(cls, path, mode=L.MODE_COMPAT, device=-1):
+        """A State that continues from a snapshot written by save(): the next update() yields the same bits as
+        the saved run's next update() would have (the step has no hidden state beyond these arrays)."""
+        with np.load(path, allow_pickle=False) as d:
+            if int(d["format"][0]) != 1:
+                raise ValueError("unknown snapshot format")
+            return cls(d["pos"], d["radius"], world=tuple(d["world"]), gravity=tuple(d["gravity"]), mode=mode,
+                       prev=d["prev"], device=device)
 
     def close(self):
         self.ctx.close()

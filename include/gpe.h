@@ -247,6 +247,18 @@ gpe_status gpe_reset_timings(gpe_ctx *ctx);
 /* Synchronises, then writes up to *count entries; *count receives the number available. */
 gpe_status gpe_get_timings(gpe_ctx *ctx, gpe_timing *out, uint32_t *count);
 
+/* The reference's `--features benchmark` build writes every finished frame's scopes as a Chrome trace
+ * (state.rs:108-112, wgpu_profiler::chrometrace): one entry per recorded scope instance, start relative to the
+ * last gpe_reset_timings (or to the gpe_set_profiling call that switched profiling on).  The newest 65536
+ * instances are kept.  Same calling convention as gpe_get_timings; gpu-physics-engine_amd/engine.py
+ * (Context.write_chrome_trace) turns them into the JSON chrome://tracing loads. */
+typedef struct gpe_trace_event {
+    char   name[64];
+    double start_ms;
+    double duration_ms;
+} gpe_trace_event;
+gpe_status gpe_get_trace(gpe_ctx *ctx, gpe_trace_event *out, uint32_t *count);
+
 #ifdef __cplusplus
 }
 #endif
