@@ -259,8 +259,6 @@ struct NativeState {
     bool force = false;              // GPE_NATIVE_FORCE=1 (tests): no hand-over to the compat kernels
     uint32_t *host_stat = nullptr;   // pinned: [0] last reported max 24x24-cell window population
     uint32_t window_max = 0;         // the same, measured synchronously at configuration time
-    hipStream_t stream2 = nullptr;   // the launch for over-capacity tiles runs beside the dense launch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dense_hold = false;         // left the native path because windows were filling up
     uint32_t steps_since_check = 0;
 };

@@ -59,7 +59,9 @@ __device__ __forceinline__ uint32_t nat_block_exclusive_scan(uint32_t v, uint32_
     __syncthreads();
     return base + inc - v;
 }
-constexpr int kHalo = 8;                       // cells = one 8x8 Morton block
+constexpr int kHalo = 8;                       // cells = one 8x8 block: the granule of the block table lookups
+constexpr int kCellHalo = 5;                   // cells a tile really needs around itself: colour-k cells within
+                                               // 5 - k of the tile, their members' home cells within 5
 constexpr uint32_t kErrOutOfBox = 1u;          // a particle outside the configured cell box
 constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS capacity (no result!)
 constexpr uint32_t kErrBoundExceeded = 16u;    // sharded run: the device-side particle count passed the host's bound
@@ -330,7 +332,6 @@ struct CollideArgs {
     uint32_t *tile_ctl;          // kCtl* words
     uint32_t *overflow1;         // packed (ty << 16 | tx) of over-capacity 32x32 tiles
     uint32_t overflow1_cap;
-    uint32_t classified;         // k_tile_classify fills the list (two-stream mode); else the dense tiles do
     // spill arena (global memory) for the particle arrays of such tiles
     float *arena_px, *arena_py, *arena_rad;
     uint32_t *arena_id, *arena_hm, *arena_mem;   // arena_mem holds 4 entries per particle
@@ -364,17 +365,22 @@ template <int T, int CAP>
 struct TileLds {
     static constexpr int TILE = T;
     static constexpr bool kGlobal = false;
-    static constexpr int RW = T + 2 * kHalo;
+    // The blocks of tile +- 8 cells are looked up (block granule), but only particles whose home cell lies within
+    // +- 5 cells are kept: 23 % fewer particles in LDS at 32x32, and the window overflows that much later.
+    static constexpr int HALO = kCellHalo;
+    static constexpr int RW = T + 2 * HALO;
     static constexpr int NCELL = RW * RW;
-    static constexpr int NB = RW / 8;
+    static constexpr int NB = (T + 2 * kHalo) / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
-    static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads;    // particles per thread
+    static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads;    // looked-up particles per thread
+    static constexpr int RAWCAP = QMAX * kNatThreads;                     // looked-up particles a window takes
+    static_assert(RAWCAP < 8192 && NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | looked-up slot (13)");
     static constexpr int QZ = (T + 8) * (T + 8) / 4;                      // cells of one colour inside its zone
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
-    uint32_t hm[CAP];          // bits 0-15 local index of the home cell; bits 16-27 phantom-cell codes
-                               // (3 x 4 bit, (dy+1)*3+(dx+1)); bits 28-29 number of phantom cells
+    uint32_t hm[CAP];          // bits 0-10 local index of the home cell; bits 11-18 overlap mask of the 8 neighbour
+                               // cells (k_native_hash); bits 19-31 the particle's slot among the looked-up ones
     // cell[lc + 1]: members of cell lc (P1) -> first slot of its list (P2) -> one past its last slot (P3);
     // cell[0] = 0, so from P3 on the list of cell lc is mem[cell[lc] .. cell[lc + 1]).  Values stay below
     // 4 * CAP < 65536: two cells share a word (LDS atomics are 32 bit, so cell_inc adds 1 or 1 << 16 --
@@ -397,7 +403,8 @@ struct TileLds {
     }
     union {
         uint16_t mem[4 * CAP]; // member lists (local particle slots)
-        uint8_t sblk[CAP];     // P0-P1 only: region block a staged slot came from
+        uint8_t sblk[RAWCAP];  // P0-P1 only: region block a looked-up slot came from
+        static_assert(RAWCAP <= 8 * CAP, "sblk fits under mem");
     };
     uint16_t list[4 * QZ];     // active cells, one segment per colour
     uint32_t lcnt[8];          // per colour: [c] cells resolved by one lane, [4 + c] cells resolved by a lane group
@@ -415,6 +422,7 @@ template <int T>
 struct TileGlobal {
     static constexpr int TILE = T;
     static constexpr bool kGlobal = true;
+    static constexpr int HALO = kHalo;             // keeps every looked-up particle: slot == looked-up slot
     static constexpr int RW = T + 2 * kHalo;
     static constexpr int NCELL = RW * RW;
     static constexpr int NB = RW / 8;
@@ -649,7 +657,10 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     static_assert(NBLK <= 255, "sblk is 8 bit");
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int ox = tx * T - kHalo, oy = ty * T - kHalo;                // region origin (cells)
+    constexpr int H = L::HALO;                                         // cells kept around the tile
+    constexpr bool kTrim = !L::kGlobal;
+    const int ox = tx * T - H, oy = ty * T - H;                        // origin of the cell window
+    const int box = (tx * T - kHalo) >> 3, boy = (ty * T - kHalo) >> 3;   // first looked-up block
     GPE_STAMP_BEGIN();
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
@@ -657,7 +668,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     if (tid < 8) S.lcnt[tid] = 0;
     if (tid < NBLK) {
         const int bi = tid % NB, bj = tid / NB;
-        const int bx = (ox >> 3) + bi, by = (oy >> 3) + bj;           // ox, oy are multiples of 8
+        const int bx = box + bi, by = boy + bj;
         uint32_t start = 0, count = 0;
         const int lbx = bx - A.bx0, lby = by - A.by0;
         if (lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
@@ -687,7 +698,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             carry += __shfl(inc, 63, 64);
         }
         for (int d = 32; d >= 1; d >>= 1) own += __shfl_xor(own, d, 64);
-        if (lane == 0) { S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[1] = own; }
+        if (lane == 0) { S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[1] = own; S.misc[3] = 0; }
     } else if (tid < 64 + (NB - 2) * (NB - 2)) {
         // population of each 3x3-block window of this tile (what an 8x8-cell sub-tile would stage):
         // the host reads the step's maximum (lagged) to leave the native path before windows overfill
@@ -715,7 +726,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         __syncthreads();
         if (S.misc[2] == 0) return false;
     } else {
-        if (P > (uint32_t)(sizeof(S.px) / sizeof(float))) return false;
+        if (P > (uint32_t)L::RAWCAP) return false;                     // more looked-up particles than slots
     }
     {
         // slot -> block map: kNatThreads / NBLK threads share each block's slots
@@ -766,35 +777,68 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         { float acc = 0; for (int q = 0; q < QMAX; ++q) acc += pp[q].x + pr[q]; asm volatile("" :: "v"(acc)); }
         GPE_STAMP(8);
 #endif
+        // home cell: the slot's block among the looked-up ones + the cell inside the block (k_native_hash),
+        // relative to the cell window; particles whose home lies outside the window are dropped here
+        int lxq[QMAX], lyq[QMAX];
+        bool keep[QMAX];
+        uint32_t slot[QMAX];
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            if (s >= P) continue;
-            // home cell: the slot's block inside the region + the cell inside the block (k_native_hash)
-            const int lx = (int)(blk[q] % NB) * 8 + (int)(cc[q] & 7u), ly = (int)(blk[q] / NB) * 8 + (int)((cc[q] >> 3) & 7u);
+            lxq[q] = (int)(blk[q] % NB) * 8 + (int)(cc[q] & 7u) - (kHalo - H);
+            lyq[q] = (int)(blk[q] / NB) * 8 + (int)((cc[q] >> 3) & 7u) - (kHalo - H);
+            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RW && lyq[q] >= 0 && lyq[q] < RW;
+            slot[q] = s;
+        }
+        if constexpr (kTrim) {
+            // kept particles get consecutive slots: one LDS atomic per wave (the order of the slots is free)
+            uint64_t mq[QMAX];
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) { mq[q] = __ballot(keep[q]); cnt += (uint32_t)__popcll(mq[q]); }
+            uint32_t base = 0;
+            if (lane == 0 && cnt) base = atomicAdd(&S.misc[3], cnt);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                slot[q] = base + popc_below_lane(mq[q]);
+                base += (uint32_t)__popcll(mq[q]);
+                keep[q] = keep[q] && slot[q] < (uint32_t)(sizeof(S.px) / sizeof(float));   // over capacity: see below
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            if (!keep[q]) continue;
+            const uint32_t s = slot[q];
+            const int lx = lxq[q], ly = lyq[q];
             S.px[s] = pp[q].x; S.py[s] = pp[q].y; S.rad[s] = pr[q]; S.id[s] = pid[q];
             const int home = ly * RW + lx;
             S.cell_inc(home + 1);
             // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
-            uint32_t over = cc[q] >> 6;
-            const uint32_t pc = (uint32_t)__popc(over);
-            uint32_t code = 0;
+            uint32_t over = (cc[q] >> 6) & 0xFFu;
+            const uint32_t raw = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
+            S.hm[s] = (uint32_t)home | (over << 11) | (kTrim ? (raw << 19) : 0u);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (over == 0) break;
                 const int k = __ffs((int)over) - 1;
                 over &= over - 1u;
                 const int nb = k + (k >> 2);                           // neighbour index (y+1)*3 + (x+1), 4 = centre
-                code |= (uint32_t)nb << (4 * j);
                 const int y3 = (nb * 11) >> 5;                         // nb / 3 for nb < 9
                 const int nlx = lx + (nb - 3 * y3) - 1, nly = ly + y3 - 1;
                 if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) S.cell_inc(nly * RW + nlx + 1);
             }
-            S.hm[s] = (uint32_t)home | (code << 16) | ((pc < 3 ? pc : 3u) << 28);
         }
     }
     __syncthreads();
     GPE_STAMP(1);
+    // particles in the window from here on: the kept ones (the global window keeps every looked-up particle: its
+    // cell window is the looked-up blocks)
+    uint32_t PS = P;
+    if constexpr (kTrim) {
+        PS = S.misc[3];
+        if (PS > (uint32_t)(sizeof(S.px) / sizeof(float))) return false;    // more kept particles than the window stages
+    }
 
     // ---- P2: exclusive scan of the per-cell counts -> list starts ----------------------------------
     {
@@ -815,16 +859,21 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #ifdef GPE_DBG_SKIP
     if (!(GPE_DBG_SKIP & 4))
 #endif
-    for (uint32_t s = tid; s < P; s += kNatThreads) {
+    for (uint32_t s = tid; s < PS; s += kNatThreads) {
         const uint32_t hm = S.hm[s];
-        const int home = (int)(hm & 0xFFFFu);
+        const int home = (int)(hm & 0x7FFu);
         uint32_t k = S.cell_inc(home + 1);
         S.mem[k] = s;
-        const uint32_t pc = hm >> 28;
+        uint32_t over = (hm >> 11) & 0xFFu;
         const int lx = home % RW, ly = home / RW;
-        for (uint32_t q = 0; q < pc; ++q) {
-            const int nb = (int)((hm >> (16 + 4 * q)) & 15u);
-            const int nlx = lx + (nb % 3) - 1, nly = ly + (nb / 3) - 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (over == 0) break;
+            const int kb = __ffs((int)over) - 1;
+            over &= over - 1u;
+            const int nb = kb + (kb >> 2);
+            const int y3 = (nb * 11) >> 5;
+            const int nlx = lx + (nb - 3 * y3) - 1, nly = ly + y3 - 1;
             if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) {
                 const int lc = nly * RW + nlx;
                 k = S.cell_inc(lc + 1);
@@ -847,12 +896,12 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         static_assert(QC == QZ, "one list slot per zone cell of a colour");
         for (int base = 0; base < QC; base += kNatThreads) {
             const int i = base + tid;
-            const int hx = 2 * (i % ZW) + (kHalo - 4), hy = 2 * (i / ZW) + (kHalo - 4);
+            const int hx = 2 * (i % ZW) + (H - 4), hy = 2 * (i / ZW) + (H - 4);
             int lc[4];
             uint32_t cnt[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox, oy are even
+                // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox + hx, oy + hy are even
                 lc[c] = (hy + (c >> 1)) * RW + hx + (c & 1);
                 cnt[c] = 0;
                 if (i < QC) cnt[c] = S.cell_get(lc[c] + 1) - S.cell_get(lc[c]);
@@ -861,8 +910,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             for (int c = 0; c < 4; ++c) {
                 const int lx = hx + (c & 1), ly = hy + (c >> 1);
                 const int gxx = ox + lx, gyy = oy + ly;
-                const int ex = max(max(kHalo - lx, lx - (kHalo + T - 1)), 0);
-                const int ey = max(max(kHalo - ly, ly - (kHalo + T - 1)), 0);
+                const int ex = max(max(H - lx, lx - (H + T - 1)), 0);
+                const int ey = max(max(H - ly, ly - (H + T - 1)), 0);
                 // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
                 // (collision_cell_builder.wgsl:56); cells outside the colour's exactness zone are skipped
                 const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
@@ -939,19 +988,21 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
     const uint64_t n_owned = A.counts ? (uint64_t)A.counts[0] : A.n_owned;
-    for (uint32_t s = tid; s < P; s += kNatThreads) {
-        const int home = (int)(S.hm[s] & 0xFFFFu);
+    for (uint32_t s = tid; s < PS; s += kNatThreads) {
+        const uint32_t hm = S.hm[s];
+        const int home = (int)(hm & 0x7FFu);
         const int lx = home % RW, ly = home / RW;
-        if (lx >= kHalo && lx < kHalo + T && ly >= kHalo && ly < kHalo + T) {
+        if (lx >= H && lx < H + T && ly >= H && ly < H + T) {
             uint32_t id = S.id[s];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
-            if (A.order_keys) {                                        // S.id holds the order key: find the
-                int lo = 0, hi = NBLK;                                 // slot's block, re-read the local index
+            if (A.order_keys) {                                        // S.id holds the order key: find the block of
+                const uint32_t raw = kTrim ? (hm >> 19) : s;           // the looked-up slot, re-read the local index
+                int lo = 0, hi = NBLK;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (S.boff[mid] <= s) lo = mid; else hi = mid;
+                    if (S.boff[mid] <= raw) lo = mid; else hi = mid;
                 }
-                id = A.sorted_ids[S.bstart[lo] + (s - S.boff[lo])];
+                id = A.sorted_ids[S.bstart[lo] + (raw - S.boff[lo])];
             }
             const float2 c = make_float2(S.px[s], S.py[s]);
             if (A.fuse_verlet && id < n_owned) {
@@ -984,35 +1035,9 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
     const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
-    // a tile whose 48x48-cell region exceeds the window's capacity returns at once and is listed for
-    // k_collide_overflow (unless k_tile_classify has listed it already from the same block table: two-stream mode)
-    if (!process_tile(S, A, tx, ty) && !A.classified) {
+    // a tile whose window exceeds the capacity returns early and is listed for k_collide_overflow
+    if (!process_tile(S, A, tx, ty)) {
         if (threadIdx.x == 0) {
-            const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
-            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
-            else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
-        }
-    }
-}
-
-// Lists the 32x32 tiles whose region holds more particles than the main window stages (the test process_tile
-// makes on the same table), so that the dense launch and the launch for these tiles do not wait for each other.
-__global__ __launch_bounds__(kStreamBlock) void k_tile_classify(CollideArgs A)
-{
-    constexpr int NB = (kTileMain + 2 * kHalo) / 8;
-    const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
-        const int b0x = ((tx * kTileMain - kHalo) >> 3) - A.bx0, b0y = ((ty * kTileMain - kHalo) >> 3) - A.by0;
-        uint32_t P = 0;
-        for (int bj = 0; bj < NB; ++bj)
-            for (int bi = 0; bi < NB; ++bi) {
-                const int lbx = b0x + bi, lby = b0y + bj;
-                if (lbx < 0 || lby < 0 || lbx >= A.blocks_x || lby >= A.blocks_y) continue;
-                const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
-                if (mb < A.entries) { const uint2 se = A.table[mb]; P += se.y - se.x; }
-            }
-        if (P > (uint32_t)kCapMain) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
             if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
             else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
@@ -1089,9 +1114,6 @@ void native_release(gpe_ctx *c)
     if (N.overflow1) (void)hipFree(N.overflow1);
     if (N.arena) (void)hipFree(N.arena);
     if (N.host_stat) (void)hipHostFree(N.host_stat);
-    if (N.ev_fork) (void)hipEventDestroy(N.ev_fork);
-    if (N.ev_join) (void)hipEventDestroy(N.ev_join);
-    if (N.stream2) (void)hipStreamDestroy(N.stream2);
     N = NativeState();
 }
 
@@ -1338,36 +1360,16 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.tiles_x = cx1 / kTileMain - A.tile_x0 + 1;
     A.tiles_y = cy1 / kTileMain - A.tile_y0 + 1;
     const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
-    // Tiles whose 48x48-cell region exceeds the LDS capacity are redone as 16x16 tiles, 8x8 tiles, spill arena by a
-    // second launch.  GPE_OVERFLOW_STREAM=1 runs it on a second stream BESIDE the dense launch (both read the
-    // step-start positions and write disjoint particles; a classify kernel lists the tiles from the block table):
-    // that pays when many tiles overflow (clustered scenes); the stream fork/join costs ~8 us per step, more
-    // than the empty launch it hides, so the default is one stream.
-    static const bool two_streams = [] { const char *e = getenv("GPE_OVERFLOW_STREAM"); return e && e[0] == '1'; }();
-    A.classified = two_streams ? 1u : 0u;
-    const uint32_t grid = ((total + 7u) / 8u) * 8u;
-    if (two_streams) {
-        if (!N.stream2) {
-            GPE_HIP(c, hipStreamCreateWithFlags(&N.stream2, hipStreamNonBlocking));
-            GPE_HIP(c, hipEventCreateWithFlags(&N.ev_fork, hipEventDisableTiming));
-            GPE_HIP(c, hipEventCreateWithFlags(&N.ev_join, hipEventDisableTiming));
-        }
-        GPE_HIP(c, hipEventRecord(N.ev_fork, c->stream));
-        GPE_HIP(c, hipStreamWaitEvent(N.stream2, N.ev_fork, 0));
-        hipLaunchKernelGGL(k_tile_classify, dim3(stream_grid(total)), dim3(kStreamBlock), 0, N.stream2, A);
-        GPE_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_collide_overflow, dim3(512), dim3(kNatThreads), 0, N.stream2, A);
-        GPE_HIP(c, hipGetLastError());
-        GPE_HIP(c, hipEventRecord(N.ev_join, N.stream2));
-    }
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
+        const uint32_t grid = ((total + 7u) / 8u) * 8u;
         hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
-    if (two_streams) {
-        GPE_HIP(c, hipStreamWaitEvent(c->stream, N.ev_join, 0));
-    } else {
+    {
+        // tiles whose window exceeded the LDS capacity: 16x16 tiles, 8x8 tiles, spill arena.  (Measured and dropped:
+        // running this launch on a second stream beside the dense one -- the stream fork/join costs ~8 us per step,
+        // more than the normally empty launch it hides; it only pays in clustered scenes.)
         Scope s(c, "native/collide-dense-regions");
         hipLaunchKernelGGL(k_collide_overflow, dim3(512), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());

@@ -276,6 +276,16 @@ class ShardedState:
         self.fast_active = False
         if self.fast:
             self._plan_device_exchange()
+            # rehearse the segment exchange once on the zeroed buffers: a backend that rejects the call (every
+            # rank sees the same error) leaves this run on the torch exchange instead of failing in step 1
+            try:
+                self._move_segments()
+                self.e.sync()
+            except Exception as exc:                                   # noqa: BLE001 -- any backend error
+                import sys
+                print("[gpe sharded] device-resident exchange disabled (%s: %s); using the torch exchange"
+                      % (type(exc).__name__, exc), file=sys.stderr, flush=True)
+                self.fast = False
 
     # -- device-resident exchange --------------------------------------------------------------------------
     def _plan_device_exchange(self):
