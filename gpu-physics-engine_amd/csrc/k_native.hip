@@ -74,7 +74,7 @@ constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every
 constexpr int kCtlError = 8;                   // sticky
 constexpr uint64_t kArenaBytesPerSlot = 37;    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
-constexpr int kTileMain = 32, kCapMain = 1120;
+constexpr int kTileMain = 32, kCapMain = 1200;
 constexpr int kTileMid = 16, kCapMid = 1920;
 constexpr int kTileSmall = 8, kCapSmall = 2048;
 constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows above this population
@@ -906,6 +906,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 cnt[c] = 0;
                 if (i < QC) cnt[c] = S.cell_get(lc[c] + 1) - S.cell_get(lc[c]);
             }
+            uint64_t ms[4], mg[4];
+            bool single[4], group[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int lx = hx + (c & 1), ly = hy + (c >> 1);
@@ -916,25 +918,29 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 // (collision_cell_builder.wgsl:56); cells outside the colour's exactness zone are skipped
                 const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
                 const bool act = (cnt[c] >= 2) && !unused_alias && (max(ex, ey) <= 4 - c);
-                const bool grp = act && (cnt[c] >= kGroupMin) && (cnt[c] <= kGroupLanes);
                 // cells of 4..8 members go to the BACK of the colour's segment: they are resolved by a group
                 // of 8 lanes (resolve_group); the others fill the segment from the front (one lane each)
-                const uint64_t mg = __ballot(grp);
-                const uint64_t ms = __ballot(act && !grp);
-                if (ms != 0) {
-                    const int leader = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(ms));
-                    uint32_t basei = 0;
-                    if (lane == leader) basei = atomicAdd(&S.lcnt[c], (uint32_t)__popcll(ms));
-                    basei = (uint32_t)__builtin_amdgcn_readlane((int)basei, leader);
-                    if (act && !grp) S.list[c * QZ + basei + popc_below_lane(ms)] = (uint16_t)lc[c];
-                }
-                if (mg != 0) {
-                    const int leader = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mg));
-                    uint32_t basei = 0;
-                    if (lane == leader) basei = atomicAdd(&S.lcnt[4 + c], (uint32_t)__popcll(mg));
-                    basei = (uint32_t)__builtin_amdgcn_readlane((int)basei, leader);
-                    if (grp) S.list[c * QZ + (QZ - 1) - (basei + popc_below_lane(mg))] = (uint16_t)lc[c];
-                }
+                group[c] = act && (cnt[c] >= kGroupMin) && (cnt[c] <= kGroupLanes);
+                single[c] = act && !group[c];
+                mg[c] = __ballot(group[c]);
+                ms[c] = __ballot(single[c]);
+            }
+            // the eight list counters (colour x class) are bumped by eight lanes at once: one LDS round trip for
+            // the wave instead of eight dependent ones
+            uint32_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mine = (lane == c) ? (uint32_t)__popcll(ms[c]) : mine;
+                mine = (lane == 4 + c) ? (uint32_t)__popcll(mg[c]) : mine;
+            }
+            uint32_t mybase = 0;
+            if (lane < 8 && mine) mybase = atomicAdd(&S.lcnt[lane], mine);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)mybase, c);
+                const uint32_t bg = (uint32_t)__builtin_amdgcn_readlane((int)mybase, 4 + c);
+                if (single[c]) S.list[c * QZ + bs + popc_below_lane(ms[c])] = (uint16_t)lc[c];
+                if (group[c]) S.list[c * QZ + (QZ - 1) - (bg + popc_below_lane(mg[c]))] = (uint16_t)lc[c];
             }
         }
     }
