@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t nat_block_exclusive_scan(uint32_t v, uint32_
         all += x;
     }
     if (total) *total = all;
-    __syncthreads();
+    // no barrier behind the reads of s_w: its next writer (this function again) sits behind other barriers
     return base + inc - v;
 }
 constexpr int kHalo = 8;                       // cells = one 8x8 block: the granule of the block table lookups
@@ -884,6 +884,41 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     __syncthreads();
     GPE_STAMP(3);
 
+    // The tile's own particles and, when K12 is fused into the write-back, their previous positions: fetched
+    // here so that the global round trip runs under the colour passes instead of at the end of the tile.
+    const uint64_t n_owned = A.counts ? (uint64_t)A.counts[0] : A.n_owned;
+    constexpr int QOWN = QMAX;                                         // ceil(window capacity / threads)
+    uint32_t own_id[QOWN];
+    float2 own_prev[QOWN];
+    if constexpr (kTrim) {
+#pragma unroll
+        for (int q = 0; q < QOWN; ++q) {
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            own_id[q] = 0xFFFFFFFFu;
+            own_prev[q] = make_float2(0.f, 0.f);
+            if (s < PS) {
+                const uint32_t hm = S.hm[s];
+                const int home = (int)(hm & 0x7FFu);
+                const int lx = home % RW, ly = home / RW;
+                if (lx >= H && lx < H + T && ly >= H && ly < H + T) {
+                    uint32_t id = S.id[s];
+                    asm volatile("" : "+v"(id));                     // keep this an LDS read (no pointer select -> flat load)
+                    if (A.order_keys) {                                // S.id holds the order key: find the block of
+                        const uint32_t raw = hm >> 19;                 // the looked-up slot, re-read the local index
+                        int lo = 0, hi = NBLK;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (S.boff[mid] <= raw) lo = mid; else hi = mid;
+                        }
+                        id = A.sorted_ids[S.bstart[lo] + (raw - S.boff[lo])];
+                    }
+                    own_id[q] = id;
+                    if (A.fuse_verlet && id < n_owned) own_prev[q] = A.prev[id];
+                }
+            }
+        }
+    }
+
 #ifdef GPE_DBG_SKIP
     if (!(GPE_DBG_SKIP & 2))
 #endif
@@ -993,7 +1028,25 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     GPE_STAMP(5);
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
-    const uint64_t n_owned = A.counts ? (uint64_t)A.counts[0] : A.n_owned;
+    if constexpr (kTrim) {
+#pragma unroll
+        for (int q = 0; q < QOWN; ++q) {
+            const uint32_t id = own_id[q];
+            if (id == 0xFFFFFFFFu) continue;
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            const float2 c = make_float2(S.px[s], S.py[s]);
+            if (A.fuse_verlet && id < n_owned) {
+                // K12 on the resolved position: the integrated position becomes the live one, the resolved
+                // position the previous one (particle_integration.wgsl:64,76)
+                float2 o;
+                verlet_one(c.x, c.y, own_prev[q].x, own_prev[q].y, S.rad[s], A.vp, o.x, o.y);
+                A.prev[id] = c;
+                A.pos_out[id] = o;
+            } else {
+                A.pos_out[id] = c;
+            }
+        }
+    } else
     for (uint32_t s = tid; s < PS; s += kNatThreads) {
         const uint32_t hm = S.hm[s];
         const int home = (int)(hm & 0x7FFu);
@@ -1002,7 +1055,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             uint32_t id = S.id[s];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if (A.order_keys) {                                        // S.id holds the order key: find the block of
-                const uint32_t raw = kTrim ? (hm >> 19) : s;           // the looked-up slot, re-read the local index
+                const uint32_t raw = s;                                // the looked-up slot, re-read the local index
                 int lo = 0, hi = NBLK;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
@@ -1012,8 +1065,6 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             }
             const float2 c = make_float2(S.px[s], S.py[s]);
             if (A.fuse_verlet && id < n_owned) {
-                // K12 on the resolved position: the integrated position becomes the live one, the resolved
-                // position the previous one (particle_integration.wgsl:64,76)
                 const float2 q = A.prev[id];
                 float2 o;
                 verlet_one(c.x, c.y, q.x, q.y, S.rad[s], A.vp, o.x, o.y);
