@@ -449,7 +449,7 @@ static gpe_status check_device_errors(gpe_ctx *c)
     if (words[0] & 16u)
         return fail(c, GPE_ERR_STATE, "sharded run: the device-side particle count passed the host's bound");
     if (words[2])
-        return fail(c, GPE_ERR_UNSUPPORTED, "sharded exchange failed (gpe_shard_counts has the details)");
+        return fail(c, GPE_ERR_UNSUPPORTED, shard_error_text(words[2]));
     return GPE_OK;
 }
 

@@ -418,6 +418,7 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
                                  uint32_t *out_info, uint32_t *out_count, uint64_t out_capacity);
 void native_release(gpe_ctx *c);
 void shard_release(gpe_ctx *c);
+std::string shard_error_text(uint32_t flags);
 gpe_status step_for_shard(gpe_ctx *c, float dt);           // one ordinary step (gpe_api.hip do_step)
 gpe_status reconfigure_native(gpe_ctx *c);
 // verlet != nullptr: K12 is applied to the first n_owned particles as they are written back (pos_out = integrated

@@ -241,6 +241,17 @@ __global__ __launch_bounds__(kStreamBlock) void k_shard_unpack_rows(ShardArrays 
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+std::string shard_error_text(uint32_t flags)
+{
+    char msg[320];
+    snprintf(msg, sizeof(msg), "sharded exchange failed (flags 0x%x:%s%s%s%s)", flags,
+             (flags & (kShardErrSendOverflow | kShardErrRecvOverflow)) ? " a neighbour segment overflowed" : "",
+             (flags & kShardErrNoSlot) ? " a particle moved more than one block in a step" : "",
+             (flags & kShardErrCapacity) ? " particle capacity exceeded" : "",
+             (flags & kShardErrHoles) ? " too many migrants in one step" : "");
+    return msg;
+}
+
 void shard_release(gpe_ctx *c)
 {
     ShardState &S = c->shard;
@@ -447,15 +458,7 @@ gpe_status gpe_shard_counts(gpe_ctx *c, uint64_t *n_owned, uint64_t *n_total, in
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     if (n_owned) *n_owned = w[kShardOwned];
     if (n_total) *n_total = w[kShardTotal];
-    if (w[kShardError]) {
-        char msg[256];
-        snprintf(msg, sizeof(msg), "sharded exchange failed (flags 0x%x:%s%s%s%s)", w[kShardError],
-                 (w[kShardError] & (kShardErrSendOverflow | kShardErrRecvOverflow)) ? " a neighbour segment overflowed" : "",
-                 (w[kShardError] & kShardErrNoSlot) ? " a particle moved more than one block in a step" : "",
-                 (w[kShardError] & kShardErrCapacity) ? " particle capacity exceeded" : "",
-                 (w[kShardError] & kShardErrHoles) ? " too many migrants in one step" : "");
-        return fail(c, GPE_ERR_UNSUPPORTED, msg);
-    }
+    if (w[kShardError]) return fail(c, GPE_ERR_UNSUPPORTED, shard_error_text(w[kShardError]));
     if (leave) {
         // back to host-side counts (the caller re-sorts or reads the owned range): ghosts are dropped
         if (w[kShardOwned] == 0 || w[kShardOwned] > c->cap) return fail(c, GPE_ERR_STATE, "gpe_shard_counts: bad owned count");

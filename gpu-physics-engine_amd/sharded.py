@@ -297,9 +297,11 @@ class ShardedState:
             dist.all_reduce(n_all, group=self.group)
         per_block = float(n_all.item()) / float(dec.bx * dec.by)           # mean particles per 8x8-cell block
 
+        scale = float(os.environ.get("GPE_SHARD_CAP_SCALE", "1"))            # tests shrink the segments to see the error
+
         def caps(src, dst):
-            gho = int(dec.border_blocks(src, dst) * per_block * 3.0) + 2048
-            return gho // 4 + 512, gho                                        # (migrant rows, ghost rows)
+            gho = int((dec.border_blocks(src, dst) * per_block * 3.0 + 2048) * scale)
+            return gho // 4 + int(512 * scale) + 1, gho + 1                   # (migrant rows, ghost rows)
 
         def words(cm, cg):
             return 4 + 6 * cm + 4 * cg

@@ -81,3 +81,42 @@ def test_two_ranks_one_gpu_equal_single_context(gpe, tmp_path, ws, n, world, gra
     assert migrants > 0 and ghosts > 0
     assert np.array_equal(np.concatenate(poss)[order], want_pos)
     assert np.array_equal(np.concatenate(prevs)[order], want_prev)
+
+
+def _overflow_worker(rank, ws, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GPE_SHARD_CAP_SCALE"] = "0.002"             # a handful of rows per neighbour segment
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        n, world = 40_000, (420.0, 300.0)
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=5)
+        dec = sharded.Decomposition(world, np.float32(0.5) * np.float32(2.2), ws)
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, device=0)
+        st = sharded.ShardedState(eng, dec, rank, device_exchange=True)
+        msg = ""
+        try:
+            for s in range(3):
+                st.update(0.05, resort=(s == 0))
+            st.owned()
+        except gpe.GpeError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write(msg)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_exchange_overflow_is_loud(gpe, tmp_path):
+    """Segments far too small for the ghost band: the kernels drop the rows, set the sticky error word, and the
+    next synchronising call reports it -- never a silently wrong result."""
+    port = _free_port()
+    mp.spawn(_overflow_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg = open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read()
+        assert "segment overflowed" in msg, msg

@@ -107,3 +107,33 @@ def test_decomposition_tables():
         assert (dec.owner[y0:y1, x0:x1] == r).all()
         cx0, cy0, cx1, cy1 = dec.active_cells(r)
         assert cx0 <= x0 * 8 and cx1 >= min(dec.gx, x1 * 8) - 1
+
+
+def test_decomposition_plans_the_device_exchange():
+    """Host-side planning of the device-resident exchange (csrc/k_shard.hip): the neighbour relation is
+    symmetric, border-block counts match between the two sides of a pair (both ends size a segment from them),
+    and every 8x8-cell block within one block of a rectangle names that rectangle's rank in its mask."""
+    import importlib
+    sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+    cs = np.float32(0.5) * np.float32(2.2)
+    for ws, grid in ((2, None), (4, None), (8, (2, 4)), (6, (3, 2))):
+        dec = sharded.Decomposition((6096.0, 4192.0), cs, ws, grid=grid)
+        assert dec.min_region_blocks() >= 2
+        nb = [dec.neighbours(r) for r in range(ws)]
+        for r in range(ws):
+            assert r not in nb[r] and nb[r] == sorted(nb[r]) and len(nb[r]) <= 8
+            for p in nb[r]:
+                assert r in nb[p]                                           # symmetric
+                assert dec.border_blocks(r, p) > 0 and dec.border_blocks(p, r) > 0
+            for p in range(ws):
+                if p != r and p not in nb[r]:
+                    assert dec.border_blocks(r, p) == 0
+        # a block's mask never names its owner; interior blocks name nobody
+        bits = np.uint32(1) << dec.owner.astype(np.uint32)
+        assert not (dec.dest_mask & bits).any()
+        x0, y0, x1, y1 = dec.rect_blocks(0)
+        assert dec.dest_mask[y0 + 1, x0 + 1] == 0 or (x1 - x0 <= 2 or y1 - y0 <= 2)
+        # ownership of host positions follows the same float arithmetic as the kernels
+        pos = np.array([[0.0, 0.0], [6095.9, 4191.9], [3048.0 + 1e-3, 10.0]], np.float32)
+        own = dec.owner_of(pos)
+        assert own[0] == 0 and own[1] == ws - 1
