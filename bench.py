@@ -176,25 +176,42 @@ def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gr
     return elapsed, timings, world, info
 
 
-def cpu_baseline(gpe, n, budget_s=15.0):
-    """The CPU oracle (port of the reference algorithm) on this box's host cores: single thread."""
+def cpu_baseline(gpe, n, budget_s=10.0):
+    """The CPU oracle (port of the reference algorithm) on this box's host cores: all the threads of the box's CPU
+    share (OpenMP over the loops that are GPU threads in the WGSL; same bits as the serial oracle,
+    tests/test_oracle_golden.py), with the single-thread rate beside it."""
     from oracle import oracle as orc      # checker / baseline only
     world = gpe.scenes.world_for(n)
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
-    sim = orc.Sim(pos, rad, orc.default_params(world[0], world[1], 0.5))
-    sim.step(1.0 / 60.0, resort=True)     # warm-up step (includes the re-sort)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        sim.step(1.0 / 60.0, resort=False)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 1000:
-            break
-    sim.close()
-    return {"value": steps / el, "unit": "steps/s", "cores": 1, "kind": "port",
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))      # a one-GPU box's CPU share
+
+    def rate(th, budget):
+        orc.set_threads(th)
+        sim = orc.Sim(pos, rad, orc.default_params(world[0], world[1], 0.5))
+        sim.step(1.0 / 60.0, resort=True)     # warm-up step (includes the re-sort)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            sim.step(1.0 / 60.0, resort=False)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or steps >= 1000:
+                break
+        sim.close()
+        return steps / el, steps
+
+    try:
+        single, s1 = rate(1, budget_s * 0.5)
+        multi, sm = rate(threads, budget_s) if threads > 1 else (single, s1)
+    finally:
+        orc.set_threads(1)
+    return {"value": multi, "unit": "steps/s", "cores": threads, "kind": "port",
             "sample": "%d particles x %d steps of oracle/gpe_oracle.c (reference algorithm: 4N pairs, LSD radix "
-                      "sort, chunk count, scan, 4 colour passes, Verlet), 1 thread of %d host cores"
-                      % (n, steps, os.cpu_count() or 0)}
+                      "sort, chunk count, scan, 4 colour passes, Verlet) on %d OpenMP threads of %d host cores; "
+                      "1 thread: %.2f steps/s (%d steps)" % (n, sm, threads, os.cpu_count() or 0, single, s1)}
 
 
 def main():

@@ -18,6 +18,14 @@
 
 /* WGSL vec2<i32>(f32): truncation toward zero, saturating, NaN -> 0 (WGSL spec 'i32(e)').
  * The argument is already floor()ed at every call site. */
+/* Host threads for the loops whose iterations are independent (they are separate GPU threads / workgroups in the
+ * WGSL): 1 = plain serial code (default; what the parity tests use).  More threads give the same bits -- every
+ * parallel loop below writes disjoint elements -- and serve as the multi-core CPU baseline of bench.py. */
+static int g_threads = 1;
+void orc_set_threads(int threads) { g_threads = threads < 1 ? 1 : threads; }
+int orc_get_threads(void) { return g_threads; }
+#define ORC_PARALLEL_FOR _Pragma("omp parallel for schedule(static) num_threads(g_threads) if(g_threads > 1)")
+
 static inline int32_t f32_to_i32_sat(float f)
 {
     if (f != f) return 0;
@@ -95,6 +103,7 @@ uint32_t orc_cell_color(uint32_t cell_hash)
 void orc_create_home_cell_ids(const float *pos_xy, uint32_t n, float cell_size,
                               uint32_t *home_cell_ids, uint32_t *particle_ids)
 {
+    ORC_PARALLEL_FOR
     for (uint32_t obj_id = 0; obj_id < n; ++obj_id) {
         float px = pos_xy[2 * obj_id], py = pos_xy[2 * obj_id + 1];
         /* :27  vec2<i32>(floor(pos / cell_size)) -- a division, not a reciprocal multiply */
@@ -112,6 +121,7 @@ void orc_rearrange(const float *pos_xy, const float *prev_xy, const float *radiu
                    const uint32_t *particle_ids, uint32_t n,
                    float *pos_out, float *prev_out, float *radius_out)
 {
+    ORC_PARALLEL_FOR
     for (uint32_t obj_id = 0; obj_id < n; ++obj_id) {
         uint32_t r = particle_ids[obj_id];                    /* :27 */
         pos_out[2 * obj_id] = pos_xy[2 * r];                  /* :28,32 */
@@ -139,6 +149,7 @@ static int is_obj_in_cell(float px, float py, float sq_radius, int32_t cx, int32
 void orc_build_cell_ids(const float *pos_xy, const float *radius, uint32_t n, float cell_size,
                         uint32_t *cell_ids, uint32_t *object_ids)
 {
+    ORC_PARALLEL_FOR
     for (uint32_t obj_id = 0; obj_id < n; ++obj_id) {
         float px = pos_xy[2 * obj_id], py = pos_xy[2 * obj_id + 1];
         float r = radius[obj_id];
@@ -190,6 +201,7 @@ uint32_t orc_radix_num_wg(uint32_t n)
 void orc_radix_build_histogram(const uint32_t *keys, uint32_t n, uint32_t shift,
                                uint32_t num_wg, uint32_t blocks_per_wg, uint32_t *hist)
 {
+    ORC_PARALLEL_FOR
     for (uint32_t wg = 0; wg < num_wg; ++wg) {
         uint32_t shared_histogram[256];
         memset(shared_histogram, 0, sizeof(shared_histogram));              /* :35-38 */
@@ -225,11 +237,16 @@ void orc_radix_scatter(const uint32_t *keys_a, const uint32_t *payload_a, uint32
     uint32_t acc = 0;
     for (uint32_t b = 0; b < 256; ++b) { bucket_prefix[b] = acc; acc += bucket_counts[b]; } /* :116-122 */
 
-    uint32_t *wg_excl = (uint32_t *)calloc(256, sizeof(uint32_t)); /* running sum over earlier WGs */
+    /* per-bucket count of the earlier workgroups, for every workgroup (what the WGSL sums at :101-108) */
+    uint32_t *wg_excl = (uint32_t *)calloc((size_t)(num_wg + 1) * 256, sizeof(uint32_t));
+    for (uint32_t wg = 0; wg < num_wg; ++wg)
+        for (uint32_t b = 0; b < 256; ++b)
+            wg_excl[(size_t)(wg + 1) * 256 + b] = wg_excl[(size_t)wg * 256 + b] + hist[wg * 256u + b];
+    ORC_PARALLEL_FOR
     for (uint32_t wg = 0; wg < num_wg; ++wg) {
         uint32_t shared_global_offsets[256];
         for (uint32_t b = 0; b < 256; ++b)
-            shared_global_offsets[b] = bucket_prefix[b] + wg_excl[b];        /* :104-106,125-130 */
+            shared_global_offsets[b] = bucket_prefix[b] + wg_excl[(size_t)wg * 256 + b];   /* :104-106,125-130 */
 
         for (uint32_t i = 0; i < blocks_per_wg; ++i) {                       /* :138 */
             uint32_t in_block[256];                                          /* per-bucket count  */
@@ -250,7 +267,6 @@ void orc_radix_scatter(const uint32_t *keys_a, const uint32_t *payload_a, uint32
             for (uint32_t b = 0; b < 256; ++b)
                 shared_global_offsets[b] += in_block[b];                     /* :179-181 */
         }
-        for (uint32_t b = 0; b < 256; ++b) wg_excl[b] += hist[wg * 256u + b];
     }
     free(wg_excl);
 }
@@ -296,6 +312,7 @@ void orc_count_objects_per_chunk(const uint32_t *cell_ids, uint32_t total_cell_i
                                  uint32_t *chunk_obj_count)
 {
     uint32_t total_chunks = total_chunks_of(total_cell_ids);                 /* :31 */
+    ORC_PARALLEL_FOR
     for (uint32_t chunk_id = 0; chunk_id < total_chunks; ++chunk_id) {
         uint32_t first_idx = chunk_id * ORC_CHUNK_SIZE;                      /* :37 */
         /* :40 select(UNUSED, cell_ids[first_idx-1], first_idx >= 1); the out-of-bounds read
@@ -342,6 +359,7 @@ uint32_t orc_build_collision_cells(const uint32_t *cell_ids, uint32_t total_cell
         indirect_args[2] = 1u;
     }
     uint32_t total_chunks = total_chunks_of(total_cell_ids);                 /* :122 */
+    ORC_PARALLEL_FOR
     for (uint32_t chunk_id = 0; chunk_id < total_chunks; ++chunk_id) {
         uint32_t start_index = (chunk_id >= 1) ? chunk_obj_count[chunk_id - 1] : 0u; /* :128, :93 */
         uint32_t end_index = chunk_obj_count[chunk_id];                      /* :129 */
@@ -429,6 +447,7 @@ void orc_solve_collisions_color(const uint32_t *collision_cells, uint32_t num_co
 {
     /* Threads of one colour pass touch disjoint particles, so visiting
      * them sequentially is result-equivalent. */
+    ORC_PARALLEL_FOR
     for (uint32_t tid = 0; tid < num_collision_cells; ++tid) {               /* :33-36 */
         uint32_t start = collision_cells[tid];                               /* :38 */
         uint32_t cell_hash = cell_ids[start];                                /* :39 */
@@ -444,6 +463,7 @@ void orc_solve_collisions_color(const uint32_t *collision_cells, uint32_t num_co
 void orc_verlet_integration(float *pos_xy, float *prev_xy, const float *radius, uint32_t n,
                             const orc_params *p, float dt)
 {
+    ORC_PARALLEL_FOR
     for (uint32_t index = 0; index < n; ++index) {
         float cx = pos_xy[2 * index], cy = pos_xy[2 * index + 1];            /* :34 */
         float qx = prev_xy[2 * index], qy = prev_xy[2 * index + 1];          /* :35 */

@@ -44,6 +44,10 @@ typedef struct orc_params {
 void orc_params_default(orc_params *p, float world_w, float world_h, float max_radius);
 
 /* grid.rs:159-161 */
+/* host threads for the independent loops (1 = serial, the default; any count gives the same bits) */
+void orc_set_threads(int threads);
+int orc_get_threads(void);
+
 float orc_compute_cell_size(float max_radius);
 
 /* grid.wgsl:101-114 / home_cell_ids.wgsl:38-51 */

@@ -91,8 +91,20 @@ def lib():
         getattr(L, "orc_sim_" + name).restype = C.POINTER(C.c_uint32)
     L.orc_sim_num_collision_cells.argtypes = [C.c_void_p]
     L.orc_sim_num_collision_cells.restype = C.c_uint32
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_threads.restype = None
+    L.orc_get_threads.restype = C.c_int
     _lib = L
     return L
+
+
+def set_threads(n):
+    """Host threads for the oracle's independent loops (1 = serial, the default).  Same bits for any count."""
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().orc_get_threads())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -135,3 +135,27 @@ def test_prefix_sum_random_large(oracle, golden):
 def test_scan_wraps_mod_2_32(oracle):
     data = np.full(10, 0x40000000, np.uint32)
     assert np.array_equal(oracle.inclusive_scan(data), np.cumsum(data, dtype=np.uint64).astype(np.uint32))
+
+
+def test_threaded_oracle_gives_the_same_bits(oracle):
+    """The multi-core CPU baseline of bench.py (orc_set_threads > 1, OpenMP over the loops that are separate GPU
+    threads in the WGSL) must be the same computation as the serial oracle the parity tests use."""
+    rng = np.random.default_rng(9)
+    n, world = 30_000, (190.0, 160.0)
+    pos = (rng.random((n, 2), dtype=np.float32) * np.array(world, np.float32)).astype(np.float32)
+    rad = np.where(np.arange(n) % 3 == 0, np.float32(0.4), np.float32(0.5)).astype(np.float32)
+    out = []
+    try:
+        for threads in (1, 4):
+            oracle.set_threads(threads)
+            assert oracle.get_threads() == threads
+            p = oracle.default_params(world[0], world[1], 0.5, gravity=(1.0, -9.81))
+            sim = oracle.Sim(pos, rad, p)
+            for s in range(6):
+                sim.step(1 / 60, resort=(s in (0, 3)))
+            out.append((sim.pos.copy(), sim.prev.copy(), sim.cell_ids.copy(), sim.collision_cells.copy()))
+            sim.close()
+    finally:
+        oracle.set_threads(1)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
