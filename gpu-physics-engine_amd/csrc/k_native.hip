@@ -75,9 +75,14 @@ constexpr int kCtlError = 8;                   // sticky
 constexpr uint64_t kArenaBytesPerSlot = 37;    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
 constexpr int kTileMain = 32, kCapMain = 1200;
-constexpr int kTileMid = 16, kCapMid = 1920;
-constexpr int kTileSmall = 8, kCapSmall = 2048;
-constexpr uint32_t kWindowReport = kCapSmall / 4;   // tiles report windows above this population
+// The sub-tile windows take the same LDS as the main one, so the launch for over-capacity tiles also runs four
+// workgroups per CU (with 1920 / 2048-particle windows it ran two: half the waves to hide latency with).
+constexpr int kTileMid = 16, kCapMid = 1200;
+constexpr int kTileSmall = 8, kCapSmall = 1200;
+// population of a 3x3-block (24x24-cell) window = what an 8x8 sub-tile looks up (it keeps ~56 % of it):
+constexpr uint32_t kWindowReport = 512;     // tiles report windows above this population
+constexpr uint32_t kWindowHandover = 1536;  // above it the context leaves the native path (the sub-tile's slots)
+constexpr uint32_t kWindowEligible = 2048;  // a scene whose windows exceed this never enters it
 
 // ---------------------------------------------------------------------------------------------------
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
@@ -1106,7 +1111,7 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
 // indirect dispatch): one work item per 16x16 quarter.  A quarter whose 32x32-cell region is still over capacity
 // is redone by the same workgroup as four 8x8 tiles, and an 8x8 tile whose 24x24-cell window exceeds even that
 // LDS capacity gets its particle arrays from the global spill arena.  One launch, no queue, nothing to wait for.
-__global__ __launch_bounds__(kNatThreads) void k_collide_overflow(CollideArgs A)
+__global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs A)
 {
     using Mid = TileLds<kTileMid, kCapMid>;
     using Small = TileLds<kTileSmall, kCapSmall>;
@@ -1315,7 +1320,7 @@ gpe_status native_configure(gpe_ctx *c)
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
     N.window_max = wmax;
-    N.eligible = wmax <= (uint32_t)kCapSmall;
+    N.eligible = wmax <= kWindowEligible;
     // test hook: keep over-dense scenes on the native kernels (their windows then go through the spill arena)
     const char *force = getenv("GPE_NATIVE_FORCE");
     N.force = force && force[0] == '1';
@@ -1332,7 +1337,7 @@ bool native_should_run(gpe_ctx *c)
     NativeState &N = c->native;
     if (c->cfg.mode != GPE_MODE_NATIVE) return false;
     if (N.eligible) {
-        if (!N.force && N.host_stat && N.host_stat[0] > (uint32_t)(kCapSmall / 4 * 3)) {
+        if (!N.force && N.host_stat && N.host_stat[0] > kWindowHandover) {
             N.eligible = false;
             N.dense_hold = true;
             N.steps_since_check = 0;
@@ -1428,7 +1433,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // running this launch on a second stream beside the dense one -- the stream fork/join costs ~8 us per step,
         // more than the normally empty launch it hides; it only pays in clustered scenes.)
         Scope s(c, "native/collide-dense-regions");
-        hipLaunchKernelGGL(k_collide_overflow, dim3(512), dim3(kNatThreads), 0, c->stream, A);
+        hipLaunchKernelGGL(k_collide_overflow, dim3(1024), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
     return GPE_OK;
