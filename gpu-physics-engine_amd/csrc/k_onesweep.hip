@@ -45,9 +45,12 @@ constexpr int kOsBlock = 512;
 constexpr int kOsWaves = kOsBlock / 64;
 // 8192-key tiles, look-back window of 8: measured best from 1 M to 100 M keys (2048-key tiles and a 32-word
 // window were each 10-50% slower per pass at 1 M, 4 M and 16 M keys -- profiles/r01/tune_onesweep.txt)
-constexpr int kOsItems = 16;
-constexpr int kOsTile = kOsBlock * kOsItems;
-constexpr int kOsWaveSpan = 64 * kOsItems;
+constexpr int kOsItems = 16;                     // keys per thread: 8192-key tiles ...
+constexpr int kOsItemsSmall = 8;                 // ... and 4096-key tiles for small sorts: at 1 M keys 8192-key tiles
+                                                 // leave half the CUs without a workgroup (one pass 21.9 -> 20.9 us;
+                                                 // at 16 M and 100 M keys the small tiles are 20-33 % slower:
+                                                 // profiles/r01/tune_onesweep_items.txt)
+constexpr uint64_t kOsSmallSort = 3u << 20;      // sorts up to this many keys take the small tiles
 constexpr int kWin = 8;
 
 constexpr uint64_t kFlagAggregate = 1ull;        // value = this tile's count of the digit
@@ -135,7 +138,7 @@ __device__ __forceinline__ uint32_t os_block_exclusive_scan(uint32_t v, uint32_t
 //    512 threads x 16 keys = 8192 keys per tile: the look-back reads 2 KB of status per predecessor and
 //    tile, so larger tiles halve that traffic per key; keys and payloads are reordered through ONE
 //    32 KB LDS buffer, one after the other (42 KB of LDS per workgroup).
-template <bool IOTA>
+template <bool IOTA, int ITEMS>
 __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uint32_t *__restrict__ keys_in,
                                                        const uint32_t *__restrict__ vals_in,
                                                        uint32_t *__restrict__ keys_out,
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
                                                        const uint32_t *__restrict__ bases4, u64 *status,
                                                        uint32_t *ctl, uint32_t epoch)
 {
+    constexpr int kOsItems = ITEMS, kOsTile = kOsBlock * ITEMS, kOsWaveSpan = 64 * ITEMS;   // shadow the defaults
     __shared__ uint32_t s_stage[kOsTile];
     __shared__ uint32_t s_whist[kOsWaves][256];
     __shared__ u64 s_match[kOsWaves][256];                         // per-wave digit -> lane mask, zero between rounds
@@ -349,12 +353,19 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
     OS_STAMP(4);
 }
 
-static uint64_t os_tiles(uint64_t n) { return (n + kOsTile - 1) / kOsTile; }
+static int os_items(uint64_t n) { return n <= kOsSmallSort ? kOsItemsSmall : kOsItems; }
+static uint64_t os_tiles(uint64_t n)
+{
+    const uint64_t tile = (uint64_t)kOsBlock * os_items(n);
+    return (n + tile - 1) / tile;
+}
 
 gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n)
 {
     OnesweepWorkspace &ws = c->os_ws;
-    const uint64_t need = os_tiles(n) * 256 + 256;
+    // sorts of up to n keys: the small-tile sorts among them may have more tiles than the largest one
+    const uint64_t small_n = n < kOsSmallSort ? n : kOsSmallSort;
+    const uint64_t need = std::max(os_tiles(n), os_tiles(small_n)) * 256 + 256;
     if (ws.status_cap < need) {
         if (ws.status) GPE_HIP(c, hipFree(ws.status));
         ws.status = nullptr; ws.status_cap = 0;
@@ -426,7 +437,9 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
         }
         Scope s(c, "sort/onesweep");
         const bool iota = (p == 0 && iota_vals);
-        const auto kern = iota ? k_os_pass<true> : k_os_pass<false>;
+        const bool small = os_items(n) == kOsItemsSmall;
+        const auto kern = small ? (iota ? k_os_pass<true, kOsItemsSmall> : k_os_pass<false, kOsItemsSmall>)
+                                : (iota ? k_os_pass<true, kOsItems> : k_os_pass<false, kOsItems>);
         hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb, vb, n,
                            (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl, ws.epoch);
         GPE_HIP(c, hipGetLastError());
