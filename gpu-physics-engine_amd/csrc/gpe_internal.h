@@ -409,7 +409,8 @@ void onesweep_release(gpe_ctx *c);
 gpe_status onesweep_zero_hist(gpe_ctx *c);
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
-                         uint32_t **out_vals, bool bases_ready = false);
+                         uint32_t **out_vals, bool bases_ready = false, uint2 *table = nullptr,
+                         uint32_t table_entries = 0);   // table: the last pass also fills the native block table
 // native pipeline (k_native.hip)
 gpe_status native_configure(gpe_ctx *c);
 bool native_should_run(gpe_ctx *c);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
     // control words, after handing the previous step's window statistic to the host (pinned memory).  The digit
     // histograms are zeroed by the previous step's table kernel, the done-ticket by the workgroup that takes it last.
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
-        table2[i] = make_uint4(0u, 0u, 0u, 0u);
+        table2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);      // (first, one past last) = (max, 0): empty
     if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords && threadIdx.x != kCtlHashDone) {
         if (threadIdx.x == kCtlWindowMax && host_stat) host_stat[0] = tile_ctl[kCtlWindowMax];
         tile_ctl[threadIdx.x] = 0;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_window_max(const uint2 
                 const int x = bx + dx, y = by + dy;
                 if (x < 0 || y < 0 || x >= blocks_x || y >= blocks_y) continue;
                 const uint32_t m = (uint32_t)(y * blocks_x + x);
-                if (m < entries) { const uint2 se = table[m]; sum += se.y - se.x; }
+                if (m < entries) { const uint2 se = table[m]; sum += se.y > se.x ? se.y - se.x : 0u; }
             }
         best = max(best, sum);
     }
@@ -278,42 +278,10 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_check_box(const float2 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// table: the sort key is the particle's 8x8-cell block (row-major index over the box).
-// table[b] = (first, one-past-last) position of the block's particles; empty blocks stay (0,0).
+// table: the sort key is the particle's 8x8-cell block (row-major index over the box).  table[b] = (first,
+// one-past-last) position of the block's particles in the sorted order, (0xFFFFFFFF, 0) for an empty block.
+// It is filled by the last radix pass (k_onesweep.hip, k_os_pass): no launch of its own.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kStreamBlock) void k_native_block_table(const uint32_t *__restrict__ sorted_keys,
-                                                                     uint64_t n, uint2 *__restrict__ table,
-                                                                     uint32_t entries, uint32_t *__restrict__ hist4)
-{
-    // the digit histograms are dead once the radix passes have run: zero them for the next step's hash
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)kHistCopies * 4u * 256u; i += gridDim.x * blockDim.x)
-        hist4[i] = 0;
-    // four consecutive keys per lane (one 16-byte load) + the two neighbours of the quad
-    const uint64_t quads = (n + 3) / 4;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
-        const uint64_t i0 = q * 4;
-        uint32_t k[6];                                                 // keys i0-1 .. i0+4
-        if (i0 + 4 <= n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(sorted_keys + i0);
-            k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) k[1 + j] = (i0 + j < n) ? sorted_keys[i0 + j] : 0xFFFFFFFFu;
-        }
-        k[0] = (i0 > 0) ? sorted_keys[i0 - 1] : 0xFFFFFFFFu;
-        k[5] = (i0 + 4 < n) ? sorted_keys[i0 + 4] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t i = i0 + j;
-            const uint32_t b = k[1 + j];
-            if (i >= n || b >= entries) continue;
-            if (i == 0 || k[j] != b) table[b].x = (uint32_t)i;
-            if (i + 1 == n || k[2 + j] != b) table[b].y = (uint32_t)(i + 1);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // collide
 // ---------------------------------------------------------------------------------------------------
@@ -679,9 +647,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         if (lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
             const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
             if (mb < A.entries) {
-                const uint2 se = A.table[mb];
-                start = se.x;
-                count = se.y - se.x;
+                const uint2 se = A.table[mb];                        // empty blocks hold (0xFFFFFFFF, 0)
+                if (se.y > se.x) { start = se.x; count = se.y - se.x; }
             }
         }
         S.bstart[tid] = start;
@@ -1202,15 +1169,13 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     }
     uint32_t *sk = nullptr, *sv = nullptr;
     {
+        // the last radix pass also fills the block table (first / one-past-last position of every block, by
+        // atomic min / max at the ends of each tile's key runs) and zeroes the digit histograms for the next step
         Scope s(c, "native/sort");
-        GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv, true));
+        GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv, true,
+                              N.block_table, N.table_entries));
     }
-    {
-        Scope s(c, "native/table");
-        hipLaunchKernelGGL(k_native_block_table, dim3(stream_grid((n + 3) / 4)), dim3(kStreamBlock), 0, c->stream, sk, n,
-                           N.block_table, N.table_entries, c->os_ws.hist4);
-        GPE_HIP(c, hipGetLastError());
-    }
+    (void)sk;
     *sorted_ids = sv;
     return GPE_OK;
 }

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
                                                        uint32_t *__restrict__ vals_out, uint64_t n,
                                                        uint32_t shift, uint32_t pass,
                                                        const uint32_t *__restrict__ bases4, u64 *status,
-                                                       uint32_t *ctl, uint32_t epoch)
+                                                       uint32_t *ctl, uint32_t epoch, uint2 *table,
+                                                       uint32_t table_entries, uint32_t *hist_zero)
 {
     constexpr int kOsItems = ITEMS, kOsTile = kOsBlock * ITEMS, kOsWaveSpan = 64 * ITEMS;   // shadow the defaults
     __shared__ uint32_t s_stage[kOsTile];
@@ -336,8 +337,22 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
             const uint32_t kk = s_stage[j];
             dst[q] = s_delta[(kk >> shift) & 255u] + j;
             keys_out[dst[q]] = kk;
+            if (table && kk < table_entries) {
+                // Last pass of the native step's sort: the keys are block indices and land in their final
+                // places, equal keys next to each other (in the tile's staging order too, which is grouped by
+                // this digit and otherwise keeps the input order = sorted by the lower digits).  The first and
+                // the last key of a run bound the block's range from this tile; min / max over the tiles is
+                // the block table entry (initialised to (0xFFFFFFFF, 0) by the hash kernel) -- no table launch.
+                const uint32_t before = j > 0 ? s_stage[j - 1] : ~kk;
+                const uint32_t after = j + 1 < tile_n ? s_stage[j + 1] : ~kk;
+                if (before != kk) atomicMin(&table[kk].x, dst[q]);
+                if (after != kk) atomicMax(&table[kk].y, dst[q] + 1u);
+            }
         }
     }
+    // the digit histograms are dead once the passes have their bases: zero them for the next step's hash
+    if (hist_zero && tile == 0)
+        for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kOsBlock) hist_zero[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kOsItems; ++k) {
@@ -406,7 +421,7 @@ gpe_status onesweep_zero_hist(gpe_ctx *c)
 // iota_vals: the payload is the identity permutation and `vals` need not be initialised.
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
-                         uint32_t **out_vals, bool bases_ready)
+                         uint32_t **out_vals, bool bases_ready, uint2 *table, uint32_t table_entries)
 {
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
@@ -440,8 +455,10 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
         const bool small = os_items(n) == kOsItemsSmall;
         const auto kern = small ? (iota ? k_os_pass<true, kOsItemsSmall> : k_os_pass<false, kOsItemsSmall>)
                                 : (iota ? k_os_pass<true, kOsItems> : k_os_pass<false, kOsItems>);
+        const bool last = p == passes - 1;
         hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb, vb, n,
-                           (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl, ws.epoch);
+                           (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl, ws.epoch,
+                           last ? table : nullptr, table_entries, (last && table) ? ws.hist4 : nullptr);
         GPE_HIP(c, hipGetLastError());
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
