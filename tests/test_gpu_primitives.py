@@ -32,6 +32,19 @@ def test_sort_sizes_random_keys_stable(gpe, ctx, n):
     assert np.array_equal(v, vals[order])
 
 
+def test_sort_across_the_tile_size_switch(gpe, ctx):
+    """Sorts of up to 3 * 2^20 keys run on 4096-key tiles, larger ones on 8192-key tiles (k_onesweep.hip); both
+    share the epoch-tagged status array.  Sizes on either side of the switch, in an order that alternates the two."""
+    for n in (3 << 20, (3 << 20) + 1, 100_003, (3 << 20) - 1, 5_000_011, 4097):
+        rng = np.random.default_rng(n)
+        keys = rng.integers(0, 1 << 22, n, dtype=np.uint64).astype(np.uint32)     # duplicates: stability matters
+        vals = np.arange(n, dtype=np.uint32)
+        k, v = _sort(gpe, ctx, keys, vals)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(k, keys[order]), n
+        assert np.array_equal(v, vals[order]), n
+
+
 @pytest.mark.parametrize("kind", ["all_equal", "two_values", "few_bits", "nearly_sorted", "unused_tail", "top_byte"])
 def test_sort_skewed_digit_distributions(gpe, ctx, kind):
     n = 300_017
