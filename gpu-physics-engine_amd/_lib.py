@@ -116,6 +116,7 @@ SYMBOLS = [
     ("gpe_shard_begin", _I32, [_VP]),
     ("gpe_shard_unpack", _I32, [_VP]),
     ("gpe_shard_step", _I32, [_VP, _F]),
+    ("gpe_shard_peek", _I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),
     ("gpe_shard_counts", _I32, [_VP, C.POINTER(_U64), C.POINTER(_U64), _I32]),
     ("gpe_set_profiling", _I32, [_VP, _U32]),
     ("gpe_reset_timings", _I32, [_VP]),

@@ -329,6 +329,7 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
 }
 
 gpe_status step_for_shard(gpe_ctx *c, float dt) { return do_step(c, dt, 0u); }
+gpe_status grow_for_shard(gpe_ctx *c, uint64_t capacity) { return grow_particle_buffers(c, capacity); }
 
 }  // namespace gpe
 

@@ -421,6 +421,7 @@ void native_release(gpe_ctx *c);
 void shard_release(gpe_ctx *c);
 std::string shard_error_text(uint32_t flags);
 gpe_status step_for_shard(gpe_ctx *c, float dt);           // one ordinary step (gpe_api.hip do_step)
+gpe_status grow_for_shard(gpe_ctx *c, uint64_t capacity);  // reallocate the particle buffers, keeping the first c->n
 gpe_status reconfigure_native(gpe_ctx *c);
 // verlet != nullptr: K12 is applied to the first n_owned particles as they are written back (pos_out = integrated
 // position, prev = resolved position) -- the separate integration launch is then skipped

@@ -264,9 +264,11 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_window_max(const uint2 
 
 // every particle inside the cell box?  (configuration-time check, not on the step path)
 __global__ __launch_bounds__(kStreamBlock) void k_native_check_box(const float2 *__restrict__ pos, uint64_t n,
+                                                                   const uint32_t *__restrict__ n_valid_ptr,
                                                                    float cell_size, int32_t gx, int32_t gy,
                                                                    uint32_t *__restrict__ flag)
 {
+    if (n_valid_ptr && *n_valid_ptr < n) n = *n_valid_ptr;           // sharded run: the count lives on the device
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool oob = false;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -1263,7 +1265,8 @@ gpe_status native_configure(gpe_ctx *c)
     GPE_TRY(onesweep_reserve(c, c->cap));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
     hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kStreamBlock), 0, c->stream, c->pos, c->n,
-                       c->cell_size, N.gx, N.gy, N.tile_ctl + kCtlError);
+                       (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr, c->cell_size, N.gx, N.gy,
+                       N.tile_ctl + kCtlError);
     GPE_HIP(c, hipGetLastError());
     uint32_t flag = 1;
     GPE_HIP(c, hipMemcpyAsync(&flag, N.tile_ctl + kCtlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));

@@ -337,6 +337,29 @@ static uint64_t shard_bound(gpe_ctx *c)
     return std::min<uint64_t>(c->cap, total + slack);
 }
 
+// A rank that particles pile up on (gravity) outgrows its buffers: when the mirrored total (it lags by < ~64 steps)
+// passes 3/4 of the capacity, read the exact counts and reallocate at 1.5 x.  Called right behind the unpack (no
+// migrant is flagged then); purely local -- no collective, the other ranks do not notice.
+static gpe_status shard_grow_if_needed(gpe_ctx *c)
+{
+    ShardState &S = c->shard;
+    const uint32_t epoch = __atomic_load_n(&S.host_counts[kShardEpoch], __ATOMIC_ACQUIRE);
+    if ((int32_t)(epoch - S.begin_epoch) <= 0) return GPE_OK;
+    if ((uint64_t)S.host_counts[kShardTotal] * 4 < c->cap * 3) return GPE_OK;
+    uint32_t w[5] = {0, 0, 0, 0, 0};
+    GPE_HIP(c, hipMemcpyAsync(w, S.counts, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    if (w[kShardError]) return fail(c, GPE_ERR_UNSUPPORTED, shard_error_text(w[kShardError]));
+    const uint64_t total = w[kShardTotal];
+    if (total * 10 < c->cap * 7) return GPE_OK;                        // the mirror was ahead of a shrinking count
+    const uint64_t want = total + total / 2 + 4096;
+    if (want > (1ull << 30) - 1) return fail(c, GPE_ERR_INVALID_ARG, "sharded run: 4n must fit in u32");
+    c->n = std::min<uint64_t>(c->cap, std::max<uint64_t>(total, 1));  // what grow_for_shard carries over
+    GPE_TRY(grow_for_shard(c, want));
+    GPE_TRY(ensure_flag_capacity(c));
+    return reconfigure_native(c);
+}
+
 }  // namespace gpe
 
 using namespace gpe;
@@ -441,12 +464,25 @@ gpe_status gpe_shard_step(gpe_ctx *c, float dt)
     const bool on = sampled ? (c->profile_step % c->profile_every) == 0 : c->profiling;
     c->profiling = on;
     gpe_status st = launch_unpack(c);
+    if (st == GPE_OK) st = shard_grow_if_needed(c);
     c->n = shard_bound(c);
     if (st == GPE_OK) st = step_for_shard(c, dt);
     c->profiling = on;
     if (st == GPE_OK) st = launch_pack(c);
     if (sampled) c->profiling = true;
     return st;
+}
+
+gpe_status gpe_shard_peek(gpe_ctx *c, uint64_t *n_owned, uint64_t *n_total)
+{
+    // the pinned mirror as it stands: no synchronisation, the values lag by the steps in flight (at most ~64)
+    if (!c) return GPE_ERR_INVALID_ARG;
+    if (!c->shard.on || !c->shard.host_counts) return fail(c, GPE_ERR_STATE, "sharded exchange not configured");
+    const uint32_t epoch = __atomic_load_n(&c->shard.host_counts[kShardEpoch], __ATOMIC_ACQUIRE);
+    const bool fresh = c->shard.active && (int32_t)(epoch - c->shard.begin_epoch) > 0;
+    if (n_owned) *n_owned = fresh ? c->shard.host_counts[kShardOwned] : c->n_owned;
+    if (n_total) *n_total = fresh ? c->shard.host_counts[kShardTotal] : c->n_owned;
+    return GPE_OK;
 }
 
 gpe_status gpe_shard_counts(gpe_ctx *c, uint64_t *n_owned, uint64_t *n_total, int32_t leave)

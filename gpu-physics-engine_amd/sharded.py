@@ -219,6 +219,11 @@ class GpeEngine:
     def step(self, dt):
         self.ctx.call("gpe_step", float(dt), 0)
 
+    def shard_peek(self):
+        no, nt = C.c_uint64(), C.c_uint64()
+        self.ctx.call("gpe_shard_peek", C.byref(no), C.byref(nt))
+        return no.value, nt.value
+
     def shard_counts(self, leave=False):
         no, nt = C.c_uint64(), C.c_uint64()
         self.ctx.call("gpe_shard_counts", C.byref(no), C.byref(nt), 1 if leave else 0)
@@ -290,12 +295,8 @@ class ShardedState:
     # -- device-resident exchange --------------------------------------------------------------------------
     def _plan_device_exchange(self):
         e, dec, rank = self.e, self.dec, self.rank
-        n_all = torch.tensor([self.n_owned], dtype=torch.int64)
-        if self.ws > 1:
-            if dist.get_backend(self.group) == "nccl":
-                n_all = n_all.to(e.device)
-            dist.all_reduce(n_all, group=self.group)
-        per_block = float(n_all.item()) / float(dec.bx * dec.by)           # mean particles per 8x8-cell block
+        per_block = self._densest_rank_per_block()                          # particles per 8x8-cell block
+        self.planned_per_block = per_block
 
         scale = float(os.environ.get("GPE_SHARD_CAP_SCALE", "1"))            # tests shrink the segments to see the error
 
@@ -341,6 +342,17 @@ class ShardedState:
             self.send_host = torch.zeros(so, dtype=torch.int32)
             self.recv_host = torch.zeros(ro, dtype=torch.int32)
 
+    def _densest_rank_per_block(self):
+        """Particles per owned block on the most crowded rank (a collective: every rank gets the same number, so
+        both ends of every neighbour pair size their segments alike)."""
+        x0, y0, x1, y1 = self.dec.rect_blocks(self.rank)
+        d = torch.tensor([self.n_owned / float(max(1, (x1 - x0) * (y1 - y0)))], dtype=torch.float64)
+        if self.ws > 1:
+            if dist.get_backend(self.group) == "nccl":
+                d = d.to(self.e.device)
+            dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
+        return float(d.item())
+
     def _move_segments(self):
         """The neighbour segments packed by the library go to their ranks: one grouped send/recv per neighbour
         (all_to_all_single with zero-sized splits for every other rank), enqueued on the library's stream."""
@@ -367,6 +379,9 @@ class ShardedState:
             e.n_owned = self.n_owned
             self.fast_active = False
             self.resort()
+            # the scene may have piled up on some ranks since the segments were sized: re-plan (collectively)
+            if self._densest_rank_per_block() > 1.5 * self.planned_per_block:
+                self._plan_device_exchange()
         if not self.fast_active:
             e.set_counts(self.n_owned, self.n_owned)
             e.ctx.call("gpe_shard_begin")

@@ -229,6 +229,9 @@ gpe_status gpe_shard_begin(gpe_ctx *ctx);
 gpe_status gpe_shard_unpack(gpe_ctx *ctx);
 /* gpe_shard_unpack + one step (State::update without re-sort) + pack of the next segments.  No host sync. */
 gpe_status gpe_shard_step(gpe_ctx *ctx, float dt);
+/* The counts as last mirrored to pinned host memory: no synchronisation, they lag by the steps in flight (<= ~64).
+ * For capacity planning (grow the buffers before the device-side total reaches the capacity). */
+gpe_status gpe_shard_peek(gpe_ctx *ctx, uint64_t *n_owned, uint64_t *n_total);
 /* Synchronises and returns the device-side counts; leave != 0 also returns the context to host-side counts
  * (owned particles only), e.g. before a Morton re-sort or a download.  Reports exchange errors. */
 gpe_status gpe_shard_counts(gpe_ctx *ctx, uint64_t *n_owned, uint64_t *n_total, int32_t leave);

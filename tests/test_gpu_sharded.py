@@ -56,11 +56,14 @@ def _worker(rank, ws, port, n, world, gravity, steps, resort_at, dt, seed, out_d
 @pytest.mark.parametrize("ws,n,world,gravity", [
     (2, 40_000, (420.0, 300.0), (40.0, 0.0)),
     (4, 60_000, (500.0, 380.0), (25.0, -30.0)),
+    (2, 40_000, (420.0, 300.0), (0.0, -80.0)),      # everything falls onto rank 0: its buffers must grow mid-run
 ])
 def test_two_ranks_one_gpu_equal_single_context(gpe, tmp_path, ws, n, world, gravity, device_exchange):
     """device-exchange: packing / hole filling / appending by the library's kernels (csrc/k_shard.hip), counts on the
     device, one all_to_all_single per step; torch-exchange: the general formulation in sharded.py."""
     steps, dt, seed, resort_at = 14, 0.05, 5, (0, 6)
+    if gravity[1] <= -80.0:
+        steps, resort_at = 30, (0, 17)
     port = _free_port()
     mp.spawn(_worker, args=(ws, port, n, world, gravity, steps, resort_at, dt, seed, str(tmp_path), device_exchange),
              nprocs=ws, join=True)
@@ -79,6 +82,8 @@ def test_two_ranks_one_gpu_equal_single_context(gpe, tmp_path, ws, n, world, gra
     assert np.array_equal(np.sort(gid), np.arange(n))
     order = np.argsort(gid)
     assert migrants > 0 and ghosts > 0
+    if gravity[1] <= -80.0:
+        assert max(len(g) for g in gids) > 1.15 * n / ws      # the pile did form on one rank
     assert np.array_equal(np.concatenate(poss)[order], want_pos)
     assert np.array_equal(np.concatenate(prevs)[order], want_prev)
 
