@@ -357,14 +357,28 @@ class ShardedState:
         """The neighbour segments packed by the library go to their ranks: one grouped send/recv per neighbour
         (all_to_all_single with zero-sized splits for every other rank), enqueued on the library's stream."""
         with self.e.stream_ctx():
-            if self.stage_cpu:                   # gloo rehearsal on a shared GPU: through pinned host memory
-                self.send_host.copy_(self.send_buf[:self.send_words])
+            send, recv = self.send_buf[:self.send_words], self.recv_buf[:self.recv_words]
+            if self.stage_cpu:                   # gloo rehearsal on a shared GPU: through host memory
+                self.send_host.copy_(send)
                 self.e.sync()
-                dist.all_to_all_single(self.recv_host, self.send_host, self.out_splits, self.in_splits, group=self.group)
-                self.recv_buf[:self.recv_words].copy_(self.recv_host)
+                send, recv = self.send_host, self.recv_host
+            if os.environ.get("GPE_SHARD_P2P") == "1":
+                # the same transfers spelled as explicit point-to-point operations (one isend + one irecv per
+                # neighbour in one batch = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd)
+                ops, so, ro = [], 0, 0
+                for p in range(self.ws):
+                    if self.in_splits[p]:
+                        ops.append(dist.P2POp(dist.isend, send[so:so + self.in_splits[p]], p, group=self.group))
+                        so += self.in_splits[p]
+                    if self.out_splits[p]:
+                        ops.append(dist.P2POp(dist.irecv, recv[ro:ro + self.out_splits[p]], p, group=self.group))
+                        ro += self.out_splits[p]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
             else:
-                dist.all_to_all_single(self.recv_buf[:self.recv_words], self.send_buf[:self.send_words],
-                                       self.out_splits, self.in_splits, group=self.group)
+                dist.all_to_all_single(recv, send, self.out_splits, self.in_splits, group=self.group)
+            if self.stage_cpu:
+                self.recv_buf[:self.recv_words].copy_(self.recv_host)
 
     def _fast_update(self, dt, resort):
         e = self.e
