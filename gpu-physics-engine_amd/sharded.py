@@ -56,7 +56,7 @@ def _factor(world_size):
 class Decomposition:
     """Rectangles of 8x8-cell blocks: owner[block], dest_mask[block] (ranks whose region is within one block)."""
 
-    def __init__(self, world, cell_size, world_size, grid=None):
+    def __init__(self, world, cell_size, world_size, grid=None, xcuts=None, ycuts=None):
         self.world = (float(world[0]), float(world[1]))
         self.cell_size = np.float32(cell_size)
         # same arithmetic as the library's native_configure: largest home coordinate = floor(world / cell)
@@ -72,8 +72,14 @@ class Decomposition:
             raise ValueError("destination masks are 26 bits wide")
         if self.px > self.bx or self.py > self.by:
             raise ValueError("world too small for this many ranks")
-        self.xcuts = [round(i * self.bx / self.px) for i in range(self.px + 1)]
-        self.ycuts = [round(j * self.by / self.py) for j in range(self.py + 1)]
+        # block columns / rows where the rectangles are cut: equal widths unless given (ShardedState.rebalance)
+        self.xcuts = [int(v) for v in xcuts] if xcuts is not None else [round(i * self.bx / self.px) for i in range(self.px + 1)]
+        self.ycuts = [int(v) for v in ycuts] if ycuts is not None else [round(j * self.by / self.py) for j in range(self.py + 1)]
+        if (len(self.xcuts) != self.px + 1 or len(self.ycuts) != self.py + 1 or self.xcuts[0] != 0 or self.ycuts[0] != 0 or
+                self.xcuts[-1] != self.bx or self.ycuts[-1] != self.by or
+                any(b <= a for a, b in zip(self.xcuts[:-1], self.xcuts[1:])) or
+                any(b <= a for a, b in zip(self.ycuts[:-1], self.ycuts[1:]))):
+            raise ValueError("cuts must rise from 0 to the block count")
         col = np.zeros(self.bx, np.int64)
         row = np.zeros(self.by, np.int64)
         for i in range(self.px):
@@ -141,6 +147,26 @@ class Decomposition:
             return x
         max_key = split(self.gx - 1) | (split(self.gy - 1) << 1)
         return (max_key >> 6) + 1
+
+
+def quantile_cuts(hist, parts, min_width=2):
+    """Cut `len(hist)` block columns (rows) into `parts` runs of about equal particle count, every run at least
+    `min_width` blocks wide (the device-resident exchange needs two).  Pure function of its arguments: every rank
+    derives the same cuts from the all-reduced histogram."""
+    hist = np.asarray(hist, np.float64)
+    nb = len(hist)
+    if parts * min_width > nb:
+        min_width = max(1, nb // parts)
+    c = np.cumsum(hist)
+    total = c[-1] if nb else 0.0
+    cuts = [0]
+    for i in range(1, parts):
+        cut = int(np.searchsorted(c, total * i / parts, side="left")) + 1 if total > 0 else round(i * nb / parts)
+        cut = max(cut, cuts[-1] + min_width)
+        cut = min(cut, nb - (parts - i) * min_width)
+        cuts.append(cut)
+    cuts.append(nb)
+    return cuts
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -261,8 +287,9 @@ class ShardedState:
     """`State` for one rank of a sharded run.  `engine` holds this rank's owned particles (first n_owned
     slots) and exposes torch views of its arrays; everything here is device-agnostic torch code."""
 
-    def __init__(self, engine, dec, rank, group=None, device_exchange=None):
+    def __init__(self, engine, dec, rank, group=None, device_exchange=None, rebalance=1.25):
         self.e, self.dec, self.rank, self.group = engine, dec, rank, group
+        self.rebalance_above = rebalance       # re-cut at re-sort steps when max/mean owned exceeds it (None: never)
         self.ws = dec.world_size
         self.n_owned = engine.n_owned
         self.n_ghost = 0
@@ -392,9 +419,11 @@ class ShardedState:
             self.n_owned, _ = e.shard_counts(leave=True)                  # host sync: re-sort steps only
             e.n_owned = self.n_owned
             self.fast_active = False
+            e.set_counts(self.n_owned, self.n_owned)
+            recut = self.rebalance()                                      # collective; re-plans the segments itself
             self.resort()
             # the scene may have piled up on some ranks since the segments were sized: re-plan (collectively)
-            if self._densest_rank_per_block() > 1.5 * self.planned_per_block:
+            if not recut and self._densest_rank_per_block() > 1.5 * self.planned_per_block:
                 self._plan_device_exchange()
         if not self.fast_active:
             e.set_counts(self.n_owned, self.n_owned)
@@ -543,6 +572,83 @@ class ShardedState:
             self.stats["migrants"] += n_mig
             self.stats["ghosts"] += self.n_ghost
 
+    # -- load balance ---------------------------------------------------------------------------------------
+    def _all_reduce_host(self, t):
+        """Sum a small tensor over the ranks; returns it on the host."""
+        if self.ws > 1:
+            if dist.get_backend(self.group) == "nccl":
+                t = t.to(self.e.device)
+                dist.all_reduce(t, group=self.group)
+            else:
+                t = t.cpu()
+                dist.all_reduce(t, group=self.group)
+        return t.cpu()
+
+    def rebalance(self):
+        """Re-cut the rectangles so that every rank owns about the same number of particles, and move the particles
+        to their new owners.  Collective; called at re-sort steps, when every particle sits on its owner and the
+        ghosts are dropped.  The result of the run does not depend on the cuts (order keys + ghost band), so a
+        re-cut run stays bit-identical to the single-device run.  Returns True when the cuts changed."""
+        if self.rebalance_above is None or self.ws == 1:
+            return False
+        e, dec, rank, ws = self.e, self.dec, self.rank, self.ws
+        n = self.n_owned
+        with e.stream_ctx():
+            mine = torch.zeros(ws, dtype=torch.int64)
+            mine[rank] = n
+            owned = self._all_reduce_host(mine).numpy()
+            if owned.max() <= self.rebalance_above * owned.mean():
+                return False
+            a = e.arrays()
+            pos = a["pos"][:n]
+            cs = float(dec.cell_size)
+            # same float32 arithmetic as the kernels: floor(pos / cell_size) >> 3
+            bxi = torch.clamp(torch.floor(pos[:, 0] / np.float32(cs)).long() >> 3, 0, dec.bx - 1)
+            byi = torch.clamp(torch.floor(pos[:, 1] / np.float32(cs)).long() >> 3, 0, dec.by - 1)
+            hx = self._all_reduce_host(torch.bincount(bxi, minlength=dec.bx)).numpy()
+            hy = self._all_reduce_host(torch.bincount(byi, minlength=dec.by)).numpy()
+            xcuts, ycuts = quantile_cuts(hx, dec.px), quantile_cuts(hy, dec.py)
+            if xcuts == dec.xcuts and ycuts == dec.ycuts:
+                return False
+            new = Decomposition(dec.world, dec.cell_size, ws, grid=(dec.px, dec.py), xcuts=xcuts, ycuts=ycuts)
+            # new owner of every particle, particles grouped by it
+            owner_t = torch.as_tensor(new.owner.astype(np.int64), device=pos.device)
+            dest = owner_t[byi, bxi]
+            order = torch.argsort(dest, stable=True)
+            send_counts = torch.bincount(dest, minlength=ws).cpu()
+            gid_f = a["gid"][:n].view(torch.float32)
+            rows = torch.cat([a["pos"][:n], a["prev"][:n], a["radius"][:n, None], gid_f[:, None]], 1)[order].contiguous()
+            # counts matrix, then the rows themselves: one all_to_all each
+            comm_cpu = self.stage_cpu or e.device.type == "cpu"
+            sc = send_counts if comm_cpu else send_counts.to(e.device)
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            rc = rc.cpu()
+            n_new = int(rc.sum())
+            send = rows.cpu() if self.stage_cpu else rows
+            recv = torch.empty((n_new, 6), dtype=torch.float32, device=send.device)
+            dist.all_to_all_single(recv, send, [int(v) for v in rc], [int(v) for v in send_counts], group=self.group)
+            if self.stage_cpu:
+                recv = recv.to(e.device)
+            if n_new == 0:
+                raise RuntimeError("rank %d owns no particle after the re-cut (unsupported)" % rank)
+            self._ensure_capacity(int(n_new * 1.3) + 4096)
+            a = e.arrays()
+            a["pos"][:n_new] = recv[:, 0:2]
+            a["prev"][:n_new] = recv[:, 2:4]
+            a["radius"][:n_new] = recv[:, 4]
+            a["gid"][:n_new] = recv[:, 5].contiguous().view(torch.int32)
+            self.n_owned, self.n_ghost = n_new, 0
+            e.n_owned = n_new
+            e.set_counts(n_new, n_new)
+        self.dec = new
+        self.tables = e.make_tables(new, max(1 << 16, e.capacity() // 4))
+        e.set_active_cells(new.active_cells(rank))
+        if self.fast:
+            self._plan_device_exchange()
+        self.stats["recuts"] = self.stats.get("recuts", 0) + 1
+        return True
+
     def resort(self):
         """The reference's Morton re-sort (particle_sort.rs:58-69) with GLOBAL new indices."""
         e = self.e
@@ -582,6 +688,8 @@ class ShardedState:
             # every Morton block's particles must sit on their owner before indices are assigned
             if self.ws > 1:
                 self.exchange()
+                self.e.set_counts(self.n_owned, self.n_owned)             # ghosts dropped
+                self.rebalance()
             self.resort()
         if self.ws > 1:
             self.exchange()
