@@ -74,7 +74,10 @@ constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every
 constexpr int kCtlError = 8;                   // sticky
 constexpr uint64_t kArenaBytesPerSlot = 37;    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
-constexpr int kTileMain = 32, kCapMain = 1200;
+#ifndef GPE_CAP_MAIN
+#define GPE_CAP_MAIN 1200
+#endif
+constexpr int kTileMain = 32, kCapMain = GPE_CAP_MAIN;
 // The sub-tile windows take the same LDS as the main one, so the launch for over-capacity tiles also runs four
 // workgroups per CU (with 1920 / 2048-particle windows it ran two: half the waves to hide latency with).
 constexpr int kTileMid = 16, kCapMid = 1200;
