@@ -207,13 +207,16 @@ __global__ __launch_bounds__(1024) void k_shard_unpack_plan(ShardArrays A, Shard
     }
 }
 
-__global__ __launch_bounds__(kStreamBlock) void k_shard_unpack_rows(ShardArrays A, ShardSlots S,
-                                                                    const uint32_t *__restrict__ send,
+__global__ __launch_bounds__(kStreamBlock) void k_shard_unpack_rows(ShardArrays A, ShardSlots S, uint32_t *send,
                                                                     const uint32_t *__restrict__ recv,
                                                                     const uint32_t *__restrict__ plan)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // the segment headers have been consumed by k_shard_unpack_plan (the rows below start behind them): reset them
+    // for the next pack, which then needs no launch of its own for that
+    if (blockIdx.x == 0 && threadIdx.x < S.n_slots * kSegHeader)
+        send[S.send_off[threadIdx.x / kSegHeader] + (threadIdx.x % kSegHeader)] = 0;
     for (uint32_t s = 0; s < S.n_slots; ++s) {
         const bool self = s + 1 == S.n_slots;
         const uint32_t *seg = self ? send + S.send_off[s] : recv + S.recv_off[s];
@@ -295,12 +298,14 @@ static gpe_status ensure_flag_capacity(gpe_ctx *c)
     return GPE_OK;
 }
 
-static gpe_status launch_pack(gpe_ctx *c)
+static gpe_status launch_pack(gpe_ctx *c, bool reset_headers)
 {
     ShardState &S = c->shard;
     Scope s(c, "shard/pack");
-    hipLaunchKernelGGL(k_shard_zero, dim3(1), dim3(64), 0, c->stream, S.send, S.slots, S.counts);
-    GPE_HIP(c, hipGetLastError());
+    if (reset_headers) {                                               // the first pack of a run; later ones find
+        hipLaunchKernelGGL(k_shard_zero, dim3(1), dim3(64), 0, c->stream, S.send, S.slots, S.counts);   // them reset by the unpack
+        GPE_HIP(c, hipGetLastError());
+    }
     const uint64_t bound = std::min<uint64_t>(c->cap, c->n);          // owned <= total <= bound
     hipLaunchKernelGGL(k_shard_pack, dim3(stream_grid(bound)), dim3(kStreamBlock), 0, c->stream, shard_arrays(c), bound,
                        c->cell_size, S.owner, S.dest_mask, S.blocks_x, S.blocks_y, S.my_rank, S.slots, S.send, S.counts,
@@ -436,7 +441,7 @@ gpe_status gpe_shard_begin(gpe_ctx *c)
     S.begin_epoch = epoch;
     S.active = true;
     S.steps = 0;
-    return launch_pack(c);
+    return launch_pack(c, true);
 }
 
 gpe_status gpe_shard_unpack(gpe_ctx *c)
@@ -468,7 +473,7 @@ gpe_status gpe_shard_step(gpe_ctx *c, float dt)
     c->n = shard_bound(c);
     if (st == GPE_OK) st = step_for_shard(c, dt);
     c->profiling = on;
-    if (st == GPE_OK) st = launch_pack(c);
+    if (st == GPE_OK) st = launch_pack(c, false);
     if (sampled) c->profiling = true;
     return st;
 }
