@@ -63,11 +63,9 @@ def kernel_rooflines(timings, n_particles, mode):
         "sort/onesweep": (16 * pairs, "one radix pass: R key+payload 8 B, W key+payload 8 B per pair"),
         "sort/hist": (4 * pairs, "R key 4 B per pair"),
         "native/hash": (12 * n, "R pos 8 B, W cell key 4 B per particle"),
-        "native/table": (8 * n, "R sorted key 4 B, W block bounds ~4 B per particle"),
         "native/collide": (24 * n, "R pos 8 + radius 4 + id 4, W pos 8 per particle (SURVEY 8d collision row)"),
         "native/collide+verlet": (40 * n, "collision row (R pos 8 + radius 4 + id 4, W pos 8) + fused integration "
                                           "(R prev 8, W prev 8) per particle"),
-        "native/clear": (0 * n + 1, "zeroes the block table (8 B per 64 cells) + histograms"),
         "Build cell ids": (12 * n + 32 * n, "R pos 8 + radius 4, W 4 cell ids + 4 object ids"),
         "Particle integration pass": (36 * n, "R pos 8 + prev 8 + radius 4, W pos 8 + prev 8"),
         "Collision cell count objects per chunk": (16 * n + 4 * n, "R 4N keys, W N counts"),

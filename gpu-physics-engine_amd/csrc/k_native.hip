@@ -3,20 +3,23 @@
 // The reference sorts 4N (cell, object) pairs every step and resolves collisions cell by cell through
 // global memory in four colour launches (~520 B/particle/step).  Here:
 //
-//   hash     key[i] = morton(home cell of particle i)         + the four radix histograms (fused)
-//   sort     onesweep over N (key, id) pairs                  (k_onesweep.hip)
-//   table    (start,end) of every 8x8-cell Morton block in the sorted order
-//   collide  one workgroup per 32x32-cell tile: stage the tile plus an 8-cell halo in LDS
-//            (positions, radii, ids gathered through the sorted ids), rebuild the reference's
-//            per-cell member lists (home + phantom cells, members in ascending object index) in LDS,
-//            run ALL FOUR colour passes there, write back the tile's own particles.
+//   hash     key[i] = row-major index of particle i's 8x8-cell block, code[i] = its cell inside the block + the
+//            overlap mask of its 8 neighbour cells; the four radix histograms and digit bases (fused); resets
+//            the block table and the per-step control words
+//   sort     onesweep over N (key, id) pairs (k_onesweep.hip); its last pass also fills the block table:
+//            (start, end) of every block in the sorted order
+//   collide  one workgroup per 32x32-cell tile: look the blocks of tile +- 8 cells up, keep the particles
+//            whose home cell lies within 5 cells of the tile in LDS (positions, radii, ids gathered through
+//            the sorted ids), rebuild the reference's per-cell member lists (home + phantom cells, members
+//            in ascending object index), run ALL FOUR colour passes there, write back the tile's own
+//            particles with the Verlet integration (K12) applied.
 //
 // Exactness: cell membership is frozen from the step-start positions
 // (grid.wgsl:39-97), pairs of a cell run sequentially in ascending object index on live positions
 // (collision_solver.wgsl:66-118), colours run 1..4.  A colour-k cell is exact when every cell that
 // shares a particle with it was exact in colours < k; with the tile's own particles needing cells
 // within +-1, the cells needed at colour k lie within +-(5-k) of the tile and their members' home
-// cells within +-5 <= halo 8.  Halo cells are recomputed redundantly by the neighbouring tiles (same
+// cells within +-5 (the cell window; the block lookup reaches +-8).  Halo cells are recomputed redundantly by the neighbouring tiles (same
 // inputs, same operation order => same bits), so no inter-tile communication and no global colour
 // barrier is needed.  Positions are double-buffered (read pos_in, write pos_out) because neighbours
 // read a tile's step-start positions while it writes its results.
