@@ -78,7 +78,7 @@ constexpr int kCtlError = 8;                   // sticky
 constexpr uint64_t kArenaBytesPerSlot = 37;    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
 #ifndef GPE_CAP_MAIN
-#define GPE_CAP_MAIN 1200
+#define GPE_CAP_MAIN 1192
 #endif
 constexpr int kTileMain = 32, kCapMain = GPE_CAP_MAIN;
 // The sub-tile windows take the same LDS as the main one, so the launch for over-capacity tiles also runs four
@@ -87,8 +87,13 @@ constexpr int kTileMid = 16, kCapMid = 1200;
 constexpr int kTileSmall = 8, kCapSmall = 1200;
 // population of a 3x3-block (24x24-cell) window = what an 8x8 sub-tile looks up (it keeps ~56 % of it):
 constexpr uint32_t kWindowReport = 512;     // tiles report windows above this population
-constexpr uint32_t kWindowHandover = 1536;  // above it the context leaves the native path (the sub-tile's slots)
-constexpr uint32_t kWindowEligible = 2048;  // a scene whose windows exceed this never enters it
+// Windows beyond the 8x8 sub-tile's 1536 slots take their arrays from the spill arena; with the cells of up to
+// 64 members resolved by whole waves that is faster than the compat kernels for the piles gravity builds (4 M
+// particles, windows up to ~2900, cells up to ~53 members: 2.2 ms/step against 3.75).  Far denser blobs (mouse
+// attraction: thousands per cell) are one-lane O(n^2) work that the overlapping windows would repeat: those leave
+// the native path.
+constexpr uint32_t kWindowHandover = 4096;  // above it the context leaves the native path
+constexpr uint32_t kWindowEligible = 6144;  // a scene whose windows exceed this never enters it
 
 // ---------------------------------------------------------------------------------------------------
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
@@ -388,7 +393,10 @@ struct TileLds {
         static_assert(RAWCAP <= 8 * CAP, "sblk fits under mem");
     };
     uint16_t list[4 * QZ];     // active cells, one segment per colour
-    uint32_t lcnt[8];          // per colour: [c] cells resolved by one lane, [4 + c] cells resolved by a lane group
+    // cells of 9..64 members (piles): resolved by a whole wave each; WC per colour, the rest falls back to one lane
+    static constexpr int WC = T >= 32 ? 16 : 64;
+    uint16_t wlist[4 * WC];
+    uint32_t lcnt[12];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave
     uint32_t bstart[NBLK];
     uint32_t bcnt[NBLK];
     uint32_t boff[NBLK + 1];
@@ -423,7 +431,9 @@ struct TileGlobal {
     __device__ __forceinline__ void cell_set(int i, uint32_t v) { cell[i] = v; }
     __device__ __forceinline__ uint32_t cell_inc(int i) { return atomicAdd(&cell[i], 1u); }
     uint16_t list[4 * QZ];
-    uint32_t lcnt[8];          // per colour: [c] cells resolved by one lane, [4 + c] cells resolved by a lane group
+    static constexpr int WC = 64;
+    uint16_t wlist[4 * WC];
+    uint32_t lcnt[12];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave
     uint32_t bstart[NBLK];
     uint32_t bcnt[NBLK];
     uint32_t boff[NBLK + 1];
@@ -629,6 +639,59 @@ __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint
     }
 }
 
+// A cell of 9..64 members (a pile: particles pressed into one cell) resolved by a whole wave: the systolic array
+// of resolve_group over 64 lanes (wave-wide DPP shifts).  One lane would walk n (n - 1) / 2 pairs one after the
+// other -- 1225 for 50 members, ~0.25 ms, which every colour pass of every tile near the pile would wait for; the
+// wavefront schedule takes 2 n - 3 steps.  Same operations per particle in the same order, so the same bits.
+__device__ __forceinline__ float wave_from_lane_below(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int wave_from_lane_below(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float wave_from_lane_above(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
+}
+template <class L>
+__device__ __forceinline__ void resolve_wave(L &S, const uint32_t b, const uint32_t n, const float stiffness)
+{
+    const int a = lane_id();
+    const bool has = (uint32_t)a < n;
+    const uint32_t my_slot = has ? (uint32_t)S.mem[b + a] : 0u;
+    const uint32_t my_id = has ? S.id[my_slot] : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+    for (int i = 0; i < (int)n; ++i)                                    // n is wave-uniform: v_readlane
+        rank += ((uint32_t)__builtin_amdgcn_readlane((int)my_id, i) < my_id) ? 1u : 0u;
+    const uint32_t a_slot = (uint32_t)__builtin_amdgcn_ds_permute((int)(has ? rank : (uint32_t)a) << 2, (int)my_slot);
+    float ox = 0.f, oy = 0.f, r1 = 1.f;
+    if (has) { ox = S.px[a_slot]; oy = S.py[a_slot]; r1 = S.rad[a_slot]; }
+    float p1x = ox, p1y = oy;
+    const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
+    float qx = 0.f, qy = 0.f, qr = 1.f;
+    int qb = -1;
+    const int last = 2 * (int)n - 3;
+    float fx = wave_from_lane_above(ox), fy = wave_from_lane_above(oy), fr = wave_from_lane_above(r1);
+    for (int t = 0; t <= last; ++t) {
+        float ix = wave_from_lane_below(qx), iy = wave_from_lane_below(qy), ir = wave_from_lane_below(qr);
+        int ib = wave_from_lane_below(qb);
+        if (a == 0) { ix = fx; iy = fy; ir = fr; ib = (t + 1 < (int)n) ? t + 1 : -1; }
+        fx = wave_from_lane_above(fx); fy = wave_from_lane_above(fy); fr = wave_from_lane_above(fr);
+        qb = -1;
+        if (ib == a) { p1x = ix; p1y = iy; }                           // the lane's own particle has arrived
+        const bool pairing = ib > a && has;
+        bool hit;
+        (void)pair_response(pairing, p1x, p1y, ix, iy, r1, ir, r1_plain, stiffness, hit);
+        if (pairing) { qx = ix; qy = iy; qr = ir; qb = ib; }
+    }
+    if (has && (__float_as_uint(p1x) != __float_as_uint(ox) || __float_as_uint(p1y) != __float_as_uint(oy))) {
+        S.px[a_slot] = p1x;
+        S.py[a_slot] = p1y;
+    }
+}
+
 // One tile: returns false when the region exceeds the window's capacity (nothing written).
 template <class L>
 __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
@@ -646,7 +709,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
     S.cell_clear(tid);
-    if (tid < 8) S.lcnt[tid] = 0;
+    if (tid < 12) S.lcnt[tid] = 0;
     if (tid < NBLK) {
         const int bi = tid % NB, bj = tid / NB;
         const int bx = box + bi, by = boy + bj;
@@ -923,6 +986,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             }
             uint64_t ms[4], mg[4];
             bool single[4], group[4];
+            constexpr int WC = L::WC;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int lx = hx + (c & 1), ly = hy + (c >> 1);
@@ -936,7 +1000,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 // cells of 4..8 members go to the BACK of the colour's segment: they are resolved by a group
                 // of 8 lanes (resolve_group); the others fill the segment from the front (one lane each)
                 group[c] = act && (cnt[c] >= kGroupMin) && (cnt[c] <= kGroupLanes);
-                single[c] = act && !group[c];
+                // cells of 9..64 members go to a whole wave each (resolve_wave), as far as the colour's list takes
+                bool wavec = act && cnt[c] > kGroupLanes && cnt[c] <= 64u;
+                if (wavec) {
+                    const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
+                    if (k < (uint32_t)WC) S.wlist[c * WC + k] = (uint16_t)lc[c]; else wavec = false;
+                }
+                single[c] = act && !group[c] && !wavec;
                 mg[c] = __ballot(group[c]);
                 ms[c] = __ballot(single[c]);
             }
@@ -974,6 +1044,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const uint32_t ns = S.lcnt[k], group_lanes = S.lcnt[4 + k] * kGroupLanes;
+        const uint32_t nw = min(S.lcnt[8 + k], (uint32_t)L::WC);
         const uint32_t single_base = (group_lanes + 63u) & ~63u;      // waves are all-group or all-single
         const uint32_t work = single_base + ns;
         for (uint32_t i0 = 0; i0 < work; i0 += kNatThreads) {
@@ -996,6 +1067,11 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                     resolve_cell(S, b, e, A.stiffness);
                 }
             }
+        }
+        for (uint32_t i = (uint32_t)(tid >> 6); i < nw; i += kNatWaves) {     // wave-uniform
+            const int lc = S.wlist[k * L::WC + i];
+            const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
+            resolve_wave(S, b, e - b, A.stiffness);
         }
 #ifdef GPE_TILE_STAMPS
         GPE_STAMP(9 + k);
