@@ -27,6 +27,11 @@ zero for every rank that is not a neighbour (RCCL issues a send/recv pair per ne
 no host round trip per step.  The torch formulation below stays as the general path (any displacement, CPU
 tests) and as the specification the kernels are tested against.
 
+Load balance: at re-sort steps the ranks compare their particle counts and, when they have drifted apart (a pile
+under gravity), re-cut the rectangles at the particle quantiles of the all-reduced block-column / block-row
+histograms and move the particles to their new owners (`ShardedState.rebalance`).  Buffers of a rank that fills
+up between re-sorts grow by themselves (library side, gpe_shard_step).
+
 The engine behind a rank is pluggable (`engine` argument): `GpeEngine` drives libgpe.so on the rank's GPU;
 the CPU tests plug in an oracle-backed engine (tests only) to exercise this file without a GPU.
 """
