@@ -92,8 +92,11 @@ constexpr uint32_t kWindowReport = 512;     // tiles report windows above this p
 // particles, windows up to ~2900, cells up to ~53 members: 2.2 ms/step against 3.75).  Far denser blobs (mouse
 // attraction: thousands per cell) are one-lane O(n^2) work that the overlapping windows would repeat: those leave
 // the native path.
-constexpr uint32_t kWindowHandover = 4096;  // above it the context leaves the native path
-constexpr uint32_t kWindowEligible = 6144;  // a scene whose windows exceed this never enters it
+#ifndef GPE_WINDOW_HANDOVER
+#define GPE_WINDOW_HANDOVER 4096
+#endif
+constexpr uint32_t kWindowHandover = GPE_WINDOW_HANDOVER;              // above it the context leaves the native path
+constexpr uint32_t kWindowEligible = GPE_WINDOW_HANDOVER * 3 / 2;      // a scene whose windows exceed this never enters it
 
 // ---------------------------------------------------------------------------------------------------
 // hash: R pos 8 B, W key 4 B per particle; fused 4-digit histogram for the onesweep passes.
@@ -692,6 +695,102 @@ __device__ __forceinline__ void resolve_wave(L &S, const uint32_t b, const uint3
     }
 }
 
+// Cells of 65..256 members (a crushed pile), sub-tile and spill windows only: one wave walks the pair matrix in
+// 64 x 64 blocks, block row by block row.  The reference order -- pairs (a, b), a < b, ascending -- only constrains
+// pairs that share a particle: (a, b) needs (a, b-1) and (a-1, b).  Diagonal block I: resolve_wave on chunk I.
+// Block (I, J), J > I: the 64 owners of chunk I sit in the lanes (registers, for the whole block row), the members
+// of chunk J enter at lane 0 one per step, meet one owner per step on their way up the lanes, and are stored back
+// when they leave the last owner's lane: 64 + |J| - 1 steps.  Row-major block order gives every pair its two
+// predecessors, so every particle sees its updates in the reference's order: same bits, ~n^2/64 steps instead
+// of n (n - 1) / 2 pairs in one lane.
+constexpr uint32_t kWaveCellMax = 256;
+template <class L>
+__device__ __forceinline__ void resolve_wave_blocked(L &S, const uint32_t b, const uint32_t n, const float stiffness)
+{
+    const int a = lane_id();
+    constexpr int K = (int)kWaveCellMax / 64;
+    // members into ascending object index: rank count over the whole cell, four members per lane
+    {
+        uint32_t slot[K], id[K], rank[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t m = (uint32_t)a + 64u * k;
+            slot[k] = m < n ? (uint32_t)S.mem[b + m] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t m = (uint32_t)a + 64u * k;
+            id[k] = m < n ? S.id[slot[k]] : 0xFFFFFFFFu;
+            rank[k] = 0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int lim = (int)min(64u, n > 64u * kk ? n - 64u * kk : 0u);       // wave-uniform
+            for (int i = 0; i < lim; ++i) {
+                const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)id[kk], i);
+#pragma unroll
+                for (int k = 0; k < K; ++k) rank[k] += other < id[k] ? 1u : 0u;
+            }
+        }
+        wave_lds_order();                                              // every read of mem above precedes the writes
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if ((uint32_t)a + 64u * k < n) S.mem[b + rank[k]] = slot[k];
+        wave_lds_order();
+    }
+    const uint32_t chunks = (n + 63u) / 64u;
+    for (uint32_t I = 0; I < chunks; ++I) {
+        const uint32_t bI = b + 64u * I, cI = min(64u, n - 64u * I);
+        resolve_wave(S, bI, cI, stiffness);                            // pairs inside chunk I (it re-ranks: already sorted)
+        if (I + 1 == chunks) break;
+        wave_lds_order();
+        // the owners of this block row
+        const bool has = (uint32_t)a < cI;
+        const uint32_t o_slot = has ? (uint32_t)S.mem[bI + a] : 0u;
+        float p1x = 0.f, p1y = 0.f, r1 = 1.f;
+        if (has) { p1x = S.px[o_slot]; p1y = S.py[o_slot]; r1 = S.rad[o_slot]; }
+        const float ox = p1x, oy = p1y;
+        const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
+        for (uint32_t J = I + 1; J < chunks; ++J) {
+            const uint32_t bJ = b + 64u * J, cJ = min(64u, n - 64u * J);
+            float qx = 0.f, qy = 0.f, qr = 1.f;
+            int qb = -1, qs = 0;
+            // lane 0 fetches the visitor one step ahead
+            float nx = 0.f, ny = 0.f, nr = 1.f;
+            int ns = 0;
+            if (a == 0) { ns = (int)S.mem[bJ]; nx = S.px[ns]; ny = S.py[ns]; nr = S.rad[ns]; }
+            const int steps = (int)(cI + cJ) - 1;
+            for (int t = 0; t < steps; ++t) {
+                float ix = wave_from_lane_below(qx), iy = wave_from_lane_below(qy), ir = wave_from_lane_below(qr);
+                int ib = wave_from_lane_below(qb), is = wave_from_lane_below(qs);
+                if (a == 0) {
+                    ix = nx; iy = ny; ir = nr; is = ns;
+                    ib = t < (int)cJ ? t : -1;
+                    if (t + 1 < (int)cJ) { ns = (int)S.mem[bJ + t + 1]; nx = S.px[ns]; ny = S.py[ns]; nr = S.rad[ns]; }
+                }
+                const bool pairing = has && ib >= 0;
+                const float bx0 = ix, by0 = iy;
+                bool hit;
+                (void)pair_response(pairing, p1x, p1y, ix, iy, r1, ir, r1_plain, stiffness, hit);
+                // the visitor leaves the block behind the last owner: store it if it moved on its way
+                if (pairing && (uint32_t)a + 1u == cI) {
+                    // (it may have been moved by lower lanes: compare with what lane 0 read is not possible here,
+                    // so store whenever this block touched it; an unchanged store is harmless)
+                    S.px[is] = ix; S.py[is] = iy;
+                }
+                (void)bx0; (void)by0;
+                qx = ix; qy = iy; qr = ir; qb = pairing ? ib : -1; qs = is;
+            }
+            wave_lds_order();
+        }
+        if (has && (__float_as_uint(p1x) != __float_as_uint(ox) || __float_as_uint(p1y) != __float_as_uint(oy))) {
+            S.px[o_slot] = p1x;
+            S.py[o_slot] = p1y;
+        }
+        wave_lds_order();
+    }
+}
+
 // One tile: returns false when the region exceeds the window's capacity (nothing written).
 template <class L>
 __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
@@ -741,7 +840,10 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             carry += __shfl(inc, 63, 64);
         }
         for (int d = 32; d >= 1; d >>= 1) own += __shfl_xor(own, d, 64);
-        if (lane == 0) { S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[1] = own; S.misc[3] = 0; }
+        if (lane == 0) {
+            S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[1] = own; S.misc[3] = 0;
+            if (!L::kGlobal) S.misc[2] = 0;                            // main tile: "a cell of more than 64 members"
+        }
     } else if (tid < 64 + (NB - 2) * (NB - 2)) {
         // population of each 3x3-block window of this tile (what an 8x8-cell sub-tile would stage):
         // the host reads the step's maximum (lagged) to leave the native path before windows overfill
@@ -1001,7 +1103,11 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 // of 8 lanes (resolve_group); the others fill the segment from the front (one lane each)
                 group[c] = act && (cnt[c] >= kGroupMin) && (cnt[c] <= kGroupLanes);
                 // cells of 9..64 members go to a whole wave each (resolve_wave), as far as the colour's list takes
-                bool wavec = act && cnt[c] > kGroupLanes && cnt[c] <= 64u;
+                // (65..256 members: blocked, in the sub-tile and spill windows only; a main tile that meets such a
+                // cell hands itself over to them)
+                constexpr uint32_t kWaveMax = (T >= 32) ? 64u : kWaveCellMax;
+                if (T >= 32 && act && cnt[c] > 64u) S.misc[2] = 1u;
+                bool wavec = act && cnt[c] > kGroupLanes && cnt[c] <= kWaveMax;
                 if (wavec) {
                     const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
                     if (k < (uint32_t)WC) S.wlist[c * WC + k] = (uint16_t)lc[c]; else wavec = false;
@@ -1031,6 +1137,10 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     }
     __syncthreads();
     GPE_STAMP(4);
+    if constexpr (T >= 32) {
+        // a cell of more than 64 members: the sub-tile windows resolve those with a wave per cell
+        if (S.misc[2]) return false;
+    }
 
     // ---- P5: the four colour passes (collision_solver.rs:224), one lane per collision cell ----------
     // The colour passes are one long dependent chain per cell (sqrt, divisions, LDS round trips): give these
@@ -1071,7 +1181,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         for (uint32_t i = (uint32_t)(tid >> 6); i < nw; i += kNatWaves) {     // wave-uniform
             const int lc = S.wlist[k * L::WC + i];
             const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
-            resolve_wave(S, b, e - b, A.stiffness);
+            if (e - b <= 64u) resolve_wave(S, b, e - b, A.stiffness);
+            else if constexpr (T < 32) resolve_wave_blocked(S, b, e - b, A.stiffness);
         }
 #ifdef GPE_TILE_STAMPS
         GPE_STAMP(9 + k);

@@ -237,3 +237,24 @@ def test_native_mouse_blob_hands_over_without_error(gpe):
         assert np.array_equal(a.positions(), b.positions()), "after %d steps" % ((chunk + 1) * 100)
     a.ctx.sync()
     a.close(); b.close()
+
+
+def test_native_crushed_cells_are_exact(gpe, oracle, monkeypatch):
+    """Cells of ~100 members (a crushed pile): whole-wave resolution (9..64 members) and its blocked form (65..256)
+    in the sub-tile and spill windows, kept on the native kernels by GPE_NATIVE_FORCE -- same bits as the oracle."""
+    monkeypatch.setenv("GPE_NATIVE_FORCE", "1")
+    rng = np.random.default_rng(21)
+    world = (40.0, 40.0)
+    # a sparse background plus three blobs of 90, 150 and 240 particles inside one cell each
+    bg = (rng.random((1500, 2), dtype=np.float32) * np.float32(40.0)).astype(np.float32)
+    blobs = [np.array(c, np.float32) + rng.random((k, 2), dtype=np.float32) * np.float32(0.9)
+             for c, k in (((11.1, 11.1), 90), ((22.1, 16.6), 150), ((30.9, 30.9), 240))]
+    pos = np.concatenate([bg] + blobs).astype(np.float32)
+    rad = np.full(len(pos), 0.5, np.float32)
+    st = _native(gpe, pos, rad, world)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    for s in range(3):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        _assert_positions(st.positions(), sim.pos, "crushed cells, step %d" % s)
+    st.ctx.sync()
+    st.close(); sim.close()
