@@ -138,6 +138,17 @@ class Decomposition:
         x0, y0, x1, y1 = self.rect_blocks(src)
         return int(((self.dest_mask[y0:y1, x0:x1] >> np.uint32(dst)) & 1).sum())
 
+    def segment_caps(self, src, dst, per_block, scale=1.0):
+        """(migrant rows, ghost rows) of the segment src -> dst of the device-resident exchange: three times the
+        mean population of src's blocks bordering dst, plus slack.  A pure function of the decomposition and of
+        `per_block`, so the sender and the receiver size the segment alike."""
+        gho = int((self.border_blocks(src, dst) * per_block * 3.0 + 2048) * scale)
+        return gho // 4 + int(512 * scale) + 1, gho + 1
+
+    @staticmethod
+    def segment_words(cap_mig, cap_gho):
+        return 4 + 6 * cap_mig + 4 * cap_gho                    # header, migrant rows, ghost rows (u32 words)
+
     def min_region_blocks(self):
         return min(min(b - a for a, b in zip(self.xcuts[:-1], self.xcuts[1:])),
                    min(b - a for a, b in zip(self.ycuts[:-1], self.ycuts[1:])))
@@ -333,11 +344,9 @@ class ShardedState:
         scale = float(os.environ.get("GPE_SHARD_CAP_SCALE", "1"))            # tests shrink the segments to see the error
 
         def caps(src, dst):
-            gho = int((dec.border_blocks(src, dst) * per_block * 3.0 + 2048) * scale)
-            return gho // 4 + int(512 * scale) + 1, gho + 1                   # (migrant rows, ghost rows)
+            return dec.segment_caps(src, dst, per_block, scale)              # (migrant rows, ghost rows)
 
-        def words(cm, cg):
-            return 4 + 6 * cm + 4 * cg
+        words = dec.segment_words
 
         nb = dec.neighbours(rank)
         plan = L.GpeShardPlan()

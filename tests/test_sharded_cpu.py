@@ -160,6 +160,16 @@ def test_decomposition_plans_the_device_exchange():
             for p in range(ws):
                 if p != r and p not in nb[r]:
                     assert dec.border_blocks(r, p) == 0
+        # segment sizes: what rank r plans to send to p is what p plans to receive from r (same pure function on both
+        # sides), every segment holds at least the slack, and bigger borders get bigger segments
+        for r in range(ws):
+            for p in nb[r]:
+                cm, cg = dec.segment_caps(r, p, per_block=24.3)
+                assert (cm, cg) == dec.segment_caps(r, p, per_block=24.3) and cg > 2048 and cm > 512
+                assert dec.segment_words(cm, cg) == 4 + 6 * cm + 4 * cg
+        big = max(dec.border_blocks(0, p) for p in nb[0]); small = min(dec.border_blocks(0, p) for p in nb[0])
+        pb, ps = [p for p in nb[0] if dec.border_blocks(0, p) == big][0], [p for p in nb[0] if dec.border_blocks(0, p) == small][0]
+        assert dec.segment_caps(0, pb, 24.3)[1] >= dec.segment_caps(0, ps, 24.3)[1]
         # a block's mask never names its owner; interior blocks name nobody
         bits = np.uint32(1) << dec.owner.astype(np.uint32)
         assert not (dec.dest_mask & bits).any()
