@@ -63,8 +63,19 @@ __device__ __forceinline__ uint32_t nat_block_exclusive_scan(uint32_t v, uint32_
     return base + inc - v;
 }
 constexpr int kHalo = 8;                       // cells = one 8x8 block: the granule of the block table lookups
-constexpr int kCellHalo = 5;                   // cells a tile really needs around itself: colour-k cells within
-                                               // 5 - k of the tile, their members' home cells within 5
+// Cells a tile really needs around itself (tiles start at even cell coordinates, T is even).  Colour - 1 =
+// (x & 1) + 2 (y & 1) (collision_solver.wgsl:55-58), a particle spans at most 2 x 2 cells, and a cell only depends on
+// cells of EARLIER colours that share a member with it -- its horizontal, vertical or diagonal neighbours, by parity:
+//   colour 4 (odd, odd)   <- colour 3 left / right, colour 2 below / above, colour 1 diagonal
+//   colour 3 (even, odd)  <- colour 2 diagonal, colour 1 below / above
+//   colour 2 (odd, even)  <- colour 1 left / right
+// The tile's own particles sit in cells within 1 of the tile [x0, x1] x [y0, y1] (x0, y0 even; x1, y1 odd), so the
+// cells that must be exact are
+//   colour 4: x in [x0-1, x1]   y in [y0-1, y1]        colour 3: x in [x0-2, x1+1] y in [y0-1, y1]
+//   colour 2: x in [x0-3, x1+2] y in [y0-2, y1+1]      colour 1: x in [x0-4, x1+3] y in [y0-2, y1+1]
+// and their members' home cells lie within [x0-5, x1+4] x [y0-3, y1+2]: the cell window.  (A square window of
+// tile +- 5 holds 16 % more cells, and the square colour zones 12 % more cells to resolve.)
+constexpr int kConeLeft = 4, kConeRight = 3, kConeDown = 2, kConeUp = 1;   // colour-1 cells beyond the tile's edges
 constexpr uint32_t kErrOutOfBox = 1u;          // a particle outside the configured cell box
 constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS capacity (no result!)
 constexpr uint32_t kErrBoundExceeded = 16u;    // sharded run: the device-side particle count passed the host's bound
@@ -356,16 +367,17 @@ struct TileLds {
     static constexpr bool kGlobal = false;
     // The blocks of tile +- 8 cells are looked up (block granule), but only particles whose home cell lies within
     // +- 5 cells are kept: 23 % fewer particles in LDS at 32x32, and the window overflows that much later.
-    static constexpr int HALO = kCellHalo;
-    static constexpr int RW = T + 2 * HALO;
-    static constexpr int NCELL = RW * RW;
+    // The exact cone is not a square (see kConeLeft ...): 5 / 4 cells left / right of the tile, 3 / 2 below / above.
+    static constexpr int HXL = kConeLeft + 1, HXR = kConeRight + 1, HYL = kConeDown + 1, HYR = kConeUp + 1;
+    static constexpr int RWX = T + HXL + HXR, RWY = T + HYL + HYR;
+    static constexpr int NCELL = RWX * RWY;
     static constexpr int NB = (T + 2 * kHalo) / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
     static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads;    // looked-up particles per thread
     static constexpr int RAWCAP = QMAX * kNatThreads;                     // looked-up particles a window takes
     static_assert(RAWCAP < 8192 && NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | looked-up slot (13)");
-    static constexpr int QZ = (T + 8) * (T + 8) / 4;                      // cells of one colour inside its zone
+    static constexpr int QZ = (T + 8) * (T + 4) / 4;                      // cells of one colour inside its zone
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
     uint32_t hm[CAP];          // bits 0-10 local index of the home cell; bits 11-18 overlap mask of the 8 neighbour
@@ -414,14 +426,15 @@ template <int T>
 struct TileGlobal {
     static constexpr int TILE = T;
     static constexpr bool kGlobal = true;
-    static constexpr int HALO = kHalo;             // keeps every looked-up particle: slot == looked-up slot
-    static constexpr int RW = T + 2 * kHalo;
-    static constexpr int NCELL = RW * RW;
-    static constexpr int NB = RW / 8;
+    // keeps every looked-up particle: slot == looked-up slot
+    static constexpr int HXL = kHalo, HXR = kHalo, HYL = kHalo, HYR = kHalo;
+    static constexpr int RWX = T + 2 * kHalo, RWY = T + 2 * kHalo;
+    static constexpr int NCELL = RWX * RWY;
+    static constexpr int NB = RWX / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;
     static constexpr int QMAX = 1;
-    static constexpr int QZ = (T + 8) * (T + 8) / 4;
+    static constexpr int QZ = (T + 8) * (T + 4) / 4;
     float *px, *py, *rad;
     uint32_t *id, *hm, *mem;
     uint8_t *sblk;
@@ -796,13 +809,13 @@ template <class L>
 __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
 {
     constexpr int T = L::TILE;
-    constexpr int RW = L::RW, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
+    constexpr int RWX = L::RWX, RWY = L::RWY, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
     static_assert(NBLK <= 255, "sblk is 8 bit");
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    constexpr int H = L::HALO;                                         // cells kept around the tile
+    constexpr int HX = L::HXL, HY = L::HYL;                            // cells kept left of / below the tile
     constexpr bool kTrim = !L::kGlobal;
-    const int ox = tx * T - H, oy = ty * T - H;                        // origin of the cell window
+    const int ox = tx * T - HX, oy = ty * T - HY;                      // origin of the cell window
     const int box = (tx * T - kHalo) >> 3, boy = (ty * T - kHalo) >> 3;   // first looked-up block
     GPE_STAMP_BEGIN();
 
@@ -930,9 +943,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            lxq[q] = (int)(blk[q] % NB) * 8 + (int)(cc[q] & 7u) - (kHalo - H);
-            lyq[q] = (int)(blk[q] / NB) * 8 + (int)((cc[q] >> 3) & 7u) - (kHalo - H);
-            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RW && lyq[q] >= 0 && lyq[q] < RW;
+            lxq[q] = (int)(blk[q] % NB) * 8 + (int)(cc[q] & 7u) - (kHalo - HX);
+            lyq[q] = (int)(blk[q] / NB) * 8 + (int)((cc[q] >> 3) & 7u) - (kHalo - HY);
+            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY;
             slot[q] = s;
         }
         if constexpr (kTrim) {
@@ -957,7 +970,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const uint32_t s = slot[q];
             const int lx = lxq[q], ly = lyq[q];
             S.px[s] = pp[q].x; S.py[s] = pp[q].y; S.rad[s] = pr[q]; S.id[s] = pid[q];
-            const int home = ly * RW + lx;
+            const int home = ly * RWX + lx;
             S.cell_inc(home + 1);
             // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
             uint32_t over = (cc[q] >> 6) & 0xFFu;
@@ -971,7 +984,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 const int nb = k + (k >> 2);                           // neighbour index (y+1)*3 + (x+1), 4 = centre
                 const int y3 = (nb * 11) >> 5;                         // nb / 3 for nb < 9
                 const int nlx = lx + (nb - 3 * y3) - 1, nly = ly + y3 - 1;
-                if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) S.cell_inc(nly * RW + nlx + 1);
+                if (nlx >= 0 && nlx < RWX && nly >= 0 && nly < RWY) S.cell_inc(nly * RWX + nlx + 1);
             }
         }
     }
@@ -1010,7 +1023,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         uint32_t k = S.cell_inc(home + 1);
         S.mem[k] = s;
         uint32_t over = (hm >> 11) & 0xFFu;
-        const int lx = home % RW, ly = home / RW;
+        const int lx = home % RWX, ly = home / RWX;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (over == 0) break;
@@ -1019,8 +1032,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const int nb = kb + (kb >> 2);
             const int y3 = (nb * 11) >> 5;
             const int nlx = lx + (nb - 3 * y3) - 1, nly = ly + y3 - 1;
-            if (nlx >= 0 && nlx < RW && nly >= 0 && nly < RW) {
-                const int lc = nly * RW + nlx;
+            if (nlx >= 0 && nlx < RWX && nly >= 0 && nly < RWY) {
+                const int lc = nly * RWX + nlx;
                 k = S.cell_inc(lc + 1);
                 S.mem[k] = s;
             }
@@ -1044,8 +1057,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             if (s < PS) {
                 const uint32_t hm = S.hm[s];
                 const int home = (int)(hm & 0x7FFu);
-                const int lx = home % RW, ly = home / RW;
-                if (lx >= H && lx < H + T && ly >= H && ly < H + T) {
+                const int lx = home % RWX, ly = home / RWX;
+                if (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) {
                     uint32_t id = S.id[s];
                     asm volatile("" : "+v"(id));                     // keep this an LDS read (no pointer select -> flat load)
                     if (A.order_keys) {                                // S.id holds the order key: find the block of
@@ -1071,18 +1084,22 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     //          (the four colours' reads are in flight together), so one ballot and one LDS atomic per colour,
     //          class and round compact them -------------------------------------------------------------
     {
-        // only cells inside the widest exactness zone (tile +- 4 cells) can be active: (T + 8)^2 / 4 per colour
-        constexpr int ZW = (T + 8) / 2, QC = ZW * ZW, QZ = L::QZ;
+        // only cells inside the widest exactness zone (colour 1: [x0-4, x1+3] x [y0-2, y1+1]) can be active:
+        // (T + 8) (T + 4) / 4 per colour
+        constexpr int ZW = (T + 8) / 2, ZH = (T + 4) / 2, QC = ZW * ZH, QZ = L::QZ;
         static_assert(QC == QZ, "one list slot per zone cell of a colour");
+        // the walk starts at the even cell (x0 - 4, y0 - 2) and visits 2 x 2 groups: colour = position in the group
+        static_assert(kConeLeft % 2 == 0 && kConeDown % 2 == 0 && T % 2 == 0, "groups start at even cells");
+        static_assert(HX > kConeLeft && HY > kConeDown && L::HXR > kConeRight && L::HYR > kConeUp, "zones inside the window");
         for (int base = 0; base < QC; base += kNatThreads) {
             const int i = base + tid;
-            const int hx = 2 * (i % ZW) + (H - 4), hy = 2 * (i / ZW) + (H - 4);
+            const int hx = 2 * (i % ZW) + (HX - kConeLeft), hy = 2 * (i / ZW) + (HY - kConeDown);
             int lc[4];
             uint32_t cnt[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox + hx, oy + hy are even
-                lc[c] = (hy + (c >> 1)) * RW + hx + (c & 1);
+                lc[c] = (hy + (c >> 1)) * RWX + hx + (c & 1);
                 cnt[c] = 0;
                 if (i < QC) cnt[c] = S.cell_get(lc[c] + 1) - S.cell_get(lc[c]);
             }
@@ -1093,12 +1110,15 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             for (int c = 0; c < 4; ++c) {
                 const int lx = hx + (c & 1), ly = hy + (c >> 1);
                 const int gxx = ox + lx, gyy = oy + ly;
-                const int ex = max(max(H - lx, lx - (H + T - 1)), 0);
-                const int ey = max(max(H - ly, ly - (H + T - 1)), 0);
+                // cells beyond the tile's edges on each side; the colour's zone (kCone*): colour c + 1 reaches
+                // 4 - c cells left, 3 - c right, 2 - (c >> 1) down, 1 - (c >> 1) up
+                const int exl = HX - lx, exr = lx - (HX + T - 1), eyl = HY - ly, eyr = ly - (HY + T - 1);
+                const bool in_zone = exl <= kConeLeft - c && exr <= kConeRight - c && eyl <= kConeDown - (c >> 1) &&
+                                     eyr <= kConeUp - (c >> 1);
                 // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
                 // (collision_cell_builder.wgsl:56); cells outside the colour's exactness zone are skipped
                 const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
-                const bool act = (cnt[c] >= 2) && !unused_alias && (max(ex, ey) <= 4 - c);
+                const bool act = (cnt[c] >= 2) && !unused_alias && in_zone;
                 // cells of 4..8 members go to the BACK of the colour's segment: they are resolved by a group
                 // of 8 lanes (resolve_group); the others fill the segment from the front (one lane each)
                 group[c] = act && (cnt[c] >= kGroupMin) && (cnt[c] <= kGroupLanes);
@@ -1217,8 +1237,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     for (uint32_t s = tid; s < PS; s += kNatThreads) {
         const uint32_t hm = S.hm[s];
         const int home = (int)(hm & 0x7FFu);
-        const int lx = home % RW, ly = home / RW;
-        if (lx >= H && lx < H + T && ly >= H && ly < H + T) {
+        const int lx = home % RWX, ly = home / RWX;
+        if (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) {
             uint32_t id = S.id[s];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if (A.order_keys) {                                        // S.id holds the order key: find the block of

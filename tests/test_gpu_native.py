@@ -258,3 +258,60 @@ def test_native_crushed_cells_are_exact(gpe, oracle, monkeypatch):
         _assert_positions(st.positions(), sim.pos, "crushed cells, step %d" % s)
     st.ctx.sync()
     st.close(); sim.close()
+
+
+def _threads():
+    import os
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def test_config0_100k_particles_1000_steps_match_oracle(gpe, oracle):
+    """BASELINE.json configs[0]: 100 k particles, gravity off, 1000 steps -- the workload the reference's own
+    CPU-adapter run would take.  The HIP NATIVE path against the oracle (OpenMP over the loops that are GPU
+    threads in the WGSL: same bits as the serial oracle, tests/test_oracle_golden.py), re-sort every 240 steps
+    (particle_system.rs:13-14 at 60 Hz), bit-exact at steps 1, 240, 241 (either side of a re-sort), 720 and 1000:
+    the run crosses four re-sorts."""
+    n = 100_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    st = _native(gpe, pos, rad, world)
+    oracle.set_threads(_threads())
+    try:
+        sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+        check_at = {1, 240, 241, 720, 1000}
+        for s in range(1000):
+            resort = (s % 240) == 0                                    # step 0 and every 240th step re-sort
+            st.update(1 / 60, resort=resort)
+            sim.step(1 / 60, resort=resort)
+            if s + 1 in check_at:
+                _assert_positions(st.positions(), sim.pos, "positions after step %d" % (s + 1))
+                _assert_positions(st.previous_positions(), sim.prev, "previous positions after step %d" % (s + 1))
+        assert np.array_equal(st.particles.download_particle_ids(), sim.particle_ids)
+        st.ctx.sync()
+        st.close(); sim.close()
+    finally:
+        oracle.set_threads(1)
+
+
+def test_config1_1m_particles_match_oracle_directly(gpe, oracle):
+    """BASELINE.json configs[1] size (1 M particles, the reference's 3048 x 1048 scene): NATIVE against the oracle
+    itself (not against the compat kernels), 3 steps, the first one re-sorting."""
+    n = 1_000_000
+    world = gpe.scenes.REF_WORLD
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    st = _native(gpe, pos, rad, world)
+    oracle.set_threads(_threads())
+    try:
+        sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+        for s in range(3):
+            st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        _assert_positions(st.positions(), sim.pos, "positions (1 M, 3 steps)")
+        _assert_positions(st.previous_positions(), sim.prev, "previous positions (1 M, 3 steps)")
+        assert np.array_equal(st.particles.download_particle_ids(), sim.particle_ids)
+        st.ctx.sync()
+        st.close(); sim.close()
+    finally:
+        oracle.set_threads(1)
