@@ -2,7 +2,11 @@
 """bench.py -- physics steps/s of the particle step on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N:
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or bare: `python bench.py --gpus N` then
+  starts its own N ranks -- child processes, spawned BEFORE this process makes any GPU call -- one cuda:<local_rank>
+  each over nccl (= RCCL), and exits non-zero unless all N joined.  `n_gpus` in the JSON is the number of ranks
+  that ran.
 
 A "step" is one State::update() (state.rs:115-131): [Morton re-sort] -> pair list + sort ->
 collision-cell list -> 4 colour passes -> Verlet, over one synthetic uniform-random particle cloud
@@ -48,7 +52,13 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the 100M-particle extra workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-particles", type=int, default=100_000_000)
-    ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--extra-steps", type=int, default=250,
+                    help="timed steps of the 100M legs (the re-sort at step 240 falls inside the window)")
+    ap.add_argument("--soak", action="store_true", help="N = 1: also run the 100M gravity-on scene for 3000 steps "
+                                                        "and report steps/s around steps 500 / 1500 / 2500")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher rehearsal on CPU (gloo): ranks join, run the timing protocol around an empty loop, "
+                         "print a line marked rehearsal -- no GPU, no physics, never a result")
     return ap.parse_args()
 
 
@@ -212,13 +222,176 @@ def cpu_baseline(gpe, n, budget_s=10.0):
                       "1 thread: %.2f steps/s (%d steps)" % (n, sm, threads, os.cpu_count() or 0, single, s1)}
 
 
+# ------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a launcher environment starts its own N ranks
+# ------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Spawn one child per rank BEFORE this process touches the GPU (a process that has initialised the GPU must
+    never fork/exec GPU work on this pool; this parent only waits).  The children inherit stdout: rank 0 prints the
+    JSON line.  Returns the exit code: 0 only if every rank exited 0."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GPE_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                log("bench.py: rank %d exited with %d -- stopping the other ranks" % (procs.index(p), code))
+                for q in alive:                       # exact PIDs of our own children, nothing else
+                    q.terminate()
+    if rc != 0:
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except Exception:
+                q.kill()
+    return rc
+
+
+def rehearse(args, rank, world_size):
+    """The launcher and the timing protocol with no GPU and no physics (CPU test of `--gpus N`)."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("GPE_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                           # test hook: a rank that never joins
+    if world_size > 1:
+        dist.init_process_group(backend="gloo")
+        joined = dist.get_world_size()
+    else:
+        joined = 1
+    if joined != args.gpus:
+        raise SystemExit("bench.py: %d ranks joined, --gpus %d" % (joined, args.gpus))
+    if world_size > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world_size > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "physics_steps_per_sec", "value": None, "unit": "steps/s", "n_gpus": joined,
+                          "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
+                          "self_launched": os.environ.get("GPE_BENCH_SELF_LAUNCHED") == "1",
+                          "note": "launcher rehearsal on CPU (gloo): no GPU, no physics -- not a result"}), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def kernel_source_digest():
+    """sha256 (16 hex digits) over the kernel sources: profiles/traffic.json records the digest its PMC numbers were
+    measured on, so a stale traffic figure is flagged instead of silently reported."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gpu-physics-engine_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def extra_entry(name, run, n_per_gpu, ngpu, steps, mode, resort_note):
+    el, tim, world, info = run
+    sps = steps / el
+    roofs = kernel_rooflines(tim, n_per_gpu, mode)
+    for kname, (tot, calls) in sorted(tim.items(), key=lambda kv: -kv[1][0]):
+        extra = "  %.0f GB/s algorithmic" % roofs[kname]["GBps"] if kname in roofs else ""
+        log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (kname, tot, calls, tot / max(1, calls), extra))
+    dom = max(roofs.items(), key=lambda kv: kv[1]["total_ms"]) if roofs else None
+    return {
+        "workload": name, "n_gpus": ngpu, "particles_per_gpu": n_per_gpu, "particles_total": n_per_gpu * ngpu,
+        "world": [world[0], world[1]], "steps": steps, "schedule": resort_note,
+        "system_steps_per_sec": round(sps, 3), "shard_steps_per_sec": round(sps * ngpu, 3),
+        "ms_per_step": round(1e3 / sps, 4),
+        "particle_steps_per_sec": round(sps * n_per_gpu * ngpu, 1),
+        "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * n_per_gpu * ngpu * sps / 1e9, 1),
+        "step_frac_of_hbm_roofline_per_gpu": round(ALGO_BYTES_PER_PARTICLE * n_per_gpu * sps / 1e9 / HBM_PEAK_GBS, 4),
+        "dominant_kernel": dom[0] if dom else None,
+        "dominant_kernel_avg_ms": round(dom[1]["avg_ms"], 4) if dom else None,
+        "dominant_kernel_GBps": round(dom[1]["GBps"], 1) if dom else None,
+        "dominant_kernel_frac": round(dom[1]["GBps"] / HBM_PEAK_GBS, 4) if dom else None,
+        "sharding": info,
+    }
+
+
+def run_soak(gpe, torch, n, mode, device, total=3000, window=100, marks=(500, 1500, 2500)):
+    """The 100M gravity-on scene does not stay a fresh cloud: it falls, piles up and is crushed.  Steps/s over
+    `window` steps around each mark, so the steady state is reported next to the fresh-cloud figure."""
+    import numpy as np
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    st = gpe.State(pos, rad, world=world, gravity=(0.0, -9.81), device=device,
+                   mode=gpe.MODE_NATIVE if mode == "native" else gpe.MODE_COMPAT)
+    del pos, rad
+    dt = 1.0 / 60.0
+    out, done = [], 0
+
+    def advance(k):
+        nonlocal done
+        # keep the global schedule "re-sort at step 0 and every 240th step"
+        while k > 0:
+            to_resort = (RESORT_EVERY - done % RESORT_EVERY) % RESORT_EVERY
+            if to_resort == 0:
+                st.run(dt, 1, resort_every=0, resort_first=True)
+                done += 1; k -= 1
+                continue
+            c = min(k, to_resort)
+            st.run(dt, c, resort_every=0, resort_first=False)
+            done += c; k -= c
+
+    for m in marks:
+        advance(m - window // 2 - done)
+        st.ctx.sync()
+        t0 = time.perf_counter()
+        advance(window)
+        st.ctx.sync()
+        el = time.perf_counter() - t0
+        out.append({"around_step": m, "steps": window, "ms_per_step": round(el / window * 1e3, 3),
+                    "steps_per_sec": round(window / el, 2)})
+        log("soak: around step %d: %.3f ms/step" % (m, el / window * 1e3))
+    advance(total - done)
+    st.ctx.sync()
+    p = st.positions()
+    assert np.isfinite(p).all(), "non-finite positions after the soak"
+    st.close()
+    return {"workload": "%d particles, gravity on, %d steps, re-sort every %d" % (n, total, RESORT_EVERY), "marks": out}
+
+
 def main():
     args = parse()
+    have_launcher_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_launcher_env:
+        raise SystemExit(launch_ranks(args))          # this parent never touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus and world_size > 1:
-        log("warning: WORLD_SIZE=%d but --gpus %d" % (world_size, args.gpus))
+    if world_size != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: the JSON would misreport the GPU count" %
+                         (world_size, args.gpus))
+    if args.rehearse:
+        return rehearse(args, rank, world_size)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
@@ -227,6 +400,8 @@ def main():
     backend = os.environ.get("GPE_BENCH_BACKEND", "nccl")
     if os.environ.get("GPE_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    elif world_size > 1 and torch.cuda.device_count() < world_size:
+        raise SystemExit("bench.py: --gpus %d but only %d GPUs are visible" % (world_size, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
@@ -237,6 +412,9 @@ def main():
         else:
             dist_mod.init_process_group(backend=backend)
         dist = dist_mod
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: %d ranks joined, --gpus %d" % (dist.get_world_size(), args.gpus))
+    ngpu = dist.get_world_size() if dist is not None else 1          # the ranks that actually run
     gpe = importlib.import_module("gpu-physics-engine_amd")
     gpe._lib.load()
 
@@ -248,21 +426,35 @@ def main():
     else:
         elapsed, timings, world = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
                                                args.mode, args.gravity, local_rank)
-    extra_run = None
+    # The 100M legs, shaped like BASELINE.json configs[2..4]: gravity on, warm-up 10 steps (the first re-sorts),
+    # then the timed window with the re-sort every 240 steps INSIDE it.
+    extras = []
     if not args.no_extra and args.extra_particles != n:
-        ne = args.extra_particles
-        log("extra workload: %d particles per GPU, gravity on ..." % ne)
+        ne, xs = args.extra_particles, args.extra_steps
+        sched = "warm-up 10 steps (first one re-sorts), %d timed steps, re-sort every %d steps of the run" % (xs, RESORT_EVERY)
         if world_size > 1:
-            extra_run = run_sharded(gpe, torch, dist, rank, world_size, ne, args.extra_steps, 5, "on", local_rank)
+            per = max(1, ne // world_size)
+            log("extra workload: %d particles in all over %d GPUs (%d per GPU), gravity on ..." % (per * world_size, world_size, per))
+            extras.append(("%d particles over %d GPUs (%d per GPU), gravity on (0,-9.81)%s" %
+                           (per * world_size, world_size, per, " = BASELINE.json configs[3]" if world_size == 4 else ""),
+                           run_sharded(gpe, torch, dist, rank, world_size, per, xs, 10, "on", local_rank), per, sched))
+            log("extra workload: %d particles per GPU (%d in all), gravity on ..." % (ne, ne * world_size))
+            extras.append(("%d particles per GPU, %d in all, gravity on (0,-9.81)%s" %
+                           (ne, ne * world_size, " = BASELINE.json configs[4]" if world_size == 8 else ""),
+                           run_sharded(gpe, torch, dist, rank, world_size, ne, xs, 10, "on", local_rank), ne, sched))
         else:
-            extra_run = run_workload(gpe, torch, None, 0, 1, ne, args.extra_steps, 5, args.mode, "on", local_rank) + (None,)
+            log("extra workload: %d particles, gravity on ..." % ne)
+            extras.append(("%d particles, gravity on (0,-9.81) = BASELINE.json configs[2]" % ne,
+                           run_workload(gpe, torch, None, 0, 1, ne, xs, 10, args.mode, "on", local_rank) + (None,), ne, sched))
+    soak = None
+    if args.soak and world_size == 1:
+        soak = run_soak(gpe, torch, args.extra_particles, args.mode, local_rank)
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    ngpu = max(1, world_size)
     ms_per_step = elapsed / args.steps * 1e3
     steps_per_s = args.steps / elapsed
     mode = "native" if world_size > 1 else args.mode
@@ -273,17 +465,26 @@ def main():
             extra = "  %.0f GB/s algorithmic" % roofs[name]["GBps"]
         log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
     dom = max(roofs.items(), key=lambda kv: kv[1]["total_ms"]) if roofs else None
-    traffic = None
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if dom and os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(mode, {}).get(dom[0], {}).get(str(n))
+            tj = json.load(open(tpath))
+            traffic = tj.get(mode, {}).get(dom[0], {}).get(str(n))
+            measured_on = tj.get("_measured_on", {})
+            digest = kernel_source_digest()
+            if traffic is not None and measured_on.get("csrc_sha16") != digest:
+                traffic_note = ("PMC traffic was measured on csrc %s (%s); this build is %s -- re-run scripts/gpu_profile.sh"
+                                % (measured_on.get("csrc_sha16"), measured_on.get("commit"), digest))
+                log("warning: " + traffic_note)
         except Exception:
             traffic = None
     roofline = None
     if dom:
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(dom[1]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_is": "HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/traffic.json "
+                                  "(not measured by this run)" + ("; STALE: " + traffic_note if traffic_note else ""),
                     "bytes_per_launch": dom[1]["bytes"], "avg_launch_ms": round(dom[1]["avg_ms"], 5),
                     "launches": dom[1]["calls"], "launches_are": "the launches of every %dth timed step" % PROFILE_EVERY}
 
@@ -291,7 +492,7 @@ def main():
     # completes n_gpus shard-steps per step (== plain steps/s at n_gpus = 1).
     result = {
         "metric": "physics_steps_per_sec", "value": round(steps_per_s * ngpu, 3), "unit": "steps/s",
-        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u32",
         "data": "synthetic",
         "config": {"workload": "%d particles per GPU, gravity %s, world %.1f x %.1f, radius 0.5, uniform random "
@@ -304,34 +505,21 @@ def main():
                    "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * n * ngpu * steps_per_s / 1e9, 2),
                    "step_frac_of_hbm_roofline": round(ALGO_BYTES_PER_PARTICLE * n * steps_per_s / 1e9 / HBM_PEAK_GBS, 5),
                    "reference_frame_ms_rx6800xt_incl_render": 3.66 if n == 1_000_000 else None,
+                   "launched_by": "bench.py itself (child ranks spawned before any GPU call)"
+                                  if os.environ.get("GPE_BENCH_SELF_LAUNCHED") == "1" else
+                                  ("torch.distributed.run / external launcher" if world_size > 1 else "single process"),
                    "sharding": shard_info},
         "roofline": roofline,
     }
-    if args.gpus == 1 and not args.no_cpu_baseline:
+    if ngpu == 1 and not args.no_cpu_baseline:
         log("cpu baseline (oracle, 1 thread) ...")
         result["cpu_baseline"] = cpu_baseline(gpe, min(n, 1_000_000))
         result["cpu_baseline"]["value"] = round(result["cpu_baseline"]["value"], 4)
-    if extra_run is not None:
-        el2, tim2, world2, info2 = extra_run
-        ne = args.extra_particles
-        sps2 = args.extra_steps / el2
-        roofs2 = kernel_rooflines(tim2, ne, mode)
-        for name, (tot, calls) in sorted(tim2.items(), key=lambda kv: -kv[1][0]):
-            extra = "  %.0f GB/s algorithmic" % roofs2[name]["GBps"] if name in roofs2 else ""
-            log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
-        dom2 = max(roofs2.items(), key=lambda kv: kv[1]["total_ms"]) if roofs2 else None
-        result["extra_workloads"] = [{
-            "workload": "%d particles per GPU (%d in all), gravity on (0,-9.81), world %.1f x %.1f (BASELINE.json "
-                        "configs[2] / [4])" % (ne, ne * ngpu, world2[0], world2[1]),
-            "n_gpus": ngpu, "steps": args.extra_steps, "system_steps_per_sec": round(sps2, 3),
-            "shard_steps_per_sec": round(sps2 * ngpu, 3), "ms_per_step": round(1e3 / sps2, 4),
-            "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * ne * ngpu * sps2 / 1e9, 1),
-            "step_frac_of_hbm_roofline_per_gpu": round(ALGO_BYTES_PER_PARTICLE * ne * sps2 / 1e9 / HBM_PEAK_GBS, 4),
-            "dominant_kernel": dom2[0] if dom2 else None,
-            "dominant_kernel_GBps": round(dom2[1]["GBps"], 1) if dom2 else None,
-            "dominant_kernel_frac": round(dom2[1]["GBps"] / HBM_PEAK_GBS, 4) if dom2 else None,
-            "sharding": info2,
-        }]
+    if extras:
+        result["extra_workloads"] = [extra_entry(name, run, per, ngpu, args.extra_steps, mode, sched)
+                                     for name, run, per, sched in extras]
+    if soak is not None:
+        result["soak"] = soak
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -58,6 +58,11 @@ class GpeShardPlan(C.Structure):
     ]
 
 
+# gpe_shard_transport_fn
+SHARD_TRANSPORT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+COMM_ID_BYTES = 128
+
+
 class GpeError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("gpe status %d: %s" % (status, message))
@@ -110,6 +115,7 @@ SYMBOLS = [
     ("gpe_use_order_keys", _I32, [_VP, _I32]),
     ("gpe_set_active_cells", _I32, [_VP, _I32, _I32, _I32, _I32]),
     ("gpe_stream_handle", _I32, [_VP, C.POINTER(_VP)]),
+    ("gpe_set_stream", _I32, [_VP, _VP]),
     ("gpe_refresh", _I32, [_VP]),
     ("gpe_shard_classify", _I32, [_VP, _VP, _VP, _I32, _I32, _U32, _VP, _VP, _VP, _U64]),
     ("gpe_shard_configure", _I32, [_VP, C.POINTER(GpeShardPlan)]),
@@ -118,6 +124,14 @@ SYMBOLS = [
     ("gpe_shard_step", _I32, [_VP, _F]),
     ("gpe_shard_peek", _I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),
     ("gpe_shard_counts", _I32, [_VP, C.POINTER(_U64), C.POINTER(_U64), _I32]),
+    ("gpe_comm_probe", _I32, []),
+    ("gpe_comm_unique_id", _I32, [_VP]),
+    ("gpe_shard_comm_init", _I32, [_VP, _VP, _U32, _U32]),
+    ("gpe_shard_comm_attach", _I32, [_VP, _VP]),
+    ("gpe_shard_comm_destroy", _I32, [_VP]),
+    ("gpe_shard_set_transport", _I32, [_VP, _VP, _VP]),
+    ("gpe_shard_exchange", _I32, [_VP]),
+    ("gpe_shard_run", _I32, [_VP, _F, _U64]),
     ("gpe_set_profiling", _I32, [_VP, _U32]),
     ("gpe_reset_timings", _I32, [_VP]),
     ("gpe_get_timings", _I32, [_VP, C.POINTER(GpeTiming), C.POINTER(_U32)]),

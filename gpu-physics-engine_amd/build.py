@@ -62,7 +62,7 @@ def build_library(force=False, jobs=4):
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(_compile, srcs))
     if _stale(LIB, objs):
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))

@@ -401,11 +401,12 @@ gpe_status gpe_create(const gpe_config *cfg, gpe_ctx **out)
     c->profile_every = local.profiling;
     if (const char *e = getenv("GPE_SORT")) c->use_onesweep = strcmp(e, "safe") != 0;
     if ((e = hipSetDevice(dev)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         std::string m = std::string("gpe_create: ") + hipGetErrorName(e);
         delete c;
         return fail(nullptr, GPE_ERR_HIP, m);
     }
+    c->stream = c->own_stream;
     *out = c;
     return GPE_OK;
 }
@@ -423,8 +424,11 @@ gpe_status gpe_destroy(gpe_ctx *c)
     scan_release(c);
     onesweep_release(c);
     native_release(c);
+    comm_release(c);
     shard_release(c);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    // a stream lent by gpe_set_stream belongs to the caller (a host framework may still hold buffers and
+    // events that name it): only the library's own stream is destroyed
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return GPE_OK;
 }
@@ -862,6 +866,18 @@ gpe_status gpe_stream_handle(gpe_ctx *c, void **hip_stream)
 {
     if (!c || !hip_stream) return GPE_ERR_INVALID_ARG;
     *hip_stream = (void *)c->stream;
+    return GPE_OK;
+}
+
+gpe_status gpe_set_stream(gpe_ctx *c, void *hip_stream)
+{
+    if (!c) return GPE_ERR_INVALID_ARG;
+    GPE_HIP(c, hipSetDevice(c->device));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    resolve_pending(c);                                   // event pairs recorded on the stream being left
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (c->trace_origin) (void)hipEventRecord(c->trace_origin, c->stream);
+    for (int i = 0; i < 2; ++i) c->shard.armed[i] = false;
     return GPE_OK;
 }
 

@@ -294,6 +294,11 @@ struct ShardState {
     uint64_t steps = 0;
     hipEvent_t fence[2] = {nullptr, nullptr};
     bool armed[2] = {false, false};
+    // moving the segments between ranks (gpe_comm.hip): an RCCL communicator or a caller-supplied transport
+    void *comm = nullptr;            // ncclComm_t
+    bool comm_owned = false;
+    gpe_shard_transport_fn transport = nullptr;
+    void *transport_user = nullptr;
 };
 
 }  // namespace gpe
@@ -301,7 +306,8 @@ struct ShardState {
 struct gpe_ctx {
     gpe_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // the stream every kernel, copy and RCCL call of this context goes to
+    hipStream_t own_stream = nullptr;    // created by gpe_create; `stream` is either this or one lent by gpe_set_stream
     std::string last_error;
 
     uint64_t n = 0;          // particles taking part in collisions (owned + ghosts in a sharded run)
@@ -419,6 +425,7 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
                                  uint32_t *out_info, uint32_t *out_count, uint64_t out_capacity);
 void native_release(gpe_ctx *c);
 void shard_release(gpe_ctx *c);
+void comm_release(gpe_ctx *c);
 std::string shard_error_text(uint32_t flags);
 gpe_status step_for_shard(gpe_ctx *c, float dt);           // one ordinary step (gpe_api.hip do_step)
 gpe_status grow_for_shard(gpe_ctx *c, uint64_t capacity);  // reallocate the particle buffers, keeping the first c->n

@@ -31,7 +31,7 @@ class Context:
     """WgpuContext::new_for_test() stand-in (wgpu_context.rs:73-101): device + queue == HIP stream."""
 
     def __init__(self, world=(3048.0, 1048.0), gravity=(0.0, 0.0), mode=L.MODE_COMPAT, device=-1,
-                 profiling=False):
+                 profiling=False, stream=None):
         self.lib = L.load()
         cfg = L.GpeConfig()
         L.check(self.lib.gpe_config_default(C.byref(cfg)))
@@ -43,6 +43,8 @@ class Context:
         h = C.c_void_p()
         L.check(self.lib.gpe_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        if stream is not None:          # a hipStream_t the caller owns and keeps alive (gpe_set_stream)
+            self.call("gpe_set_stream", C.c_void_p(int(stream)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -50,6 +52,11 @@ class Context:
             self.h = None
 
     def __del__(self):
+        # not during interpreter shutdown: the HIP runtime may already have been torn down by then, and the
+        # process is about to release everything anyway
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -202,6 +202,11 @@ class GpeEngine:
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.ctx = Context(world=world, gravity=gravity, mode=L.MODE_NATIVE, device=device, profiling=profiling)
+        # The context runs on a stream torch owns (torch never destroys its pool streams): torch's caching allocators
+        # and ProcessGroupNCCL remember the stream of every buffer they handle past the context's lifetime, so the
+        # stream must outlive the context -- lend it one instead of borrowing the library's (gpe_set_stream).
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx.call("gpe_set_stream", C.c_void_p(self.stream.cuda_stream))
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
         rad = np.ascontiguousarray(rad, np.float32)
         n = pos.shape[0]
@@ -210,9 +215,6 @@ class GpeEngine:
         self.ctx.call("gpe_set_particles", pos.ctypes.data_as(C.c_void_p), None, rad.ctypes.data_as(C.c_void_p), n)
         self.ctx.call("gpe_use_order_keys", 1)
         self.reserve(capacity or int(n * 1.3) + 4096)
-        h = C.c_void_p()
-        self.ctx.call("gpe_stream_handle", C.byref(h))
-        self.stream = torch.cuda.ExternalStream(h.value, device=self.device)
         self.n_owned = n
         with torch.cuda.stream(self.stream):
             self.arrays()["gid"][:n] = torch.as_tensor(np.ascontiguousarray(gid, np.int64), device=self.device).to(torch.int32)
@@ -293,7 +295,11 @@ class GpeEngine:
         return torch.cuda.stream(self.stream)
 
     def close(self):
-        self.ctx.close()
+        """Everything enqueued on the lent stream (the library's kernels, torch's copies, RCCL) has finished before
+        the context frees its buffers; the stream itself stays torch's."""
+        if getattr(self.ctx, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.ctx.close()
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -322,18 +328,10 @@ class ShardedState:
         self.fast = bool(device_exchange and self.ws > 1 and isinstance(engine, GpeEngine) and
                          dec.min_region_blocks() >= 2 and len(dec.neighbours(rank)) <= 8)
         self.fast_active = False
+        self.transport = None
         if self.fast:
             self._plan_device_exchange()
-            # rehearse the segment exchange once on the zeroed buffers: a backend that rejects the call (every
-            # rank sees the same error) leaves this run on the torch exchange instead of failing in step 1
-            try:
-                self._move_segments()
-                self.e.sync()
-            except Exception as exc:                                   # noqa: BLE001 -- any backend error
-                import sys
-                print("[gpe sharded] device-resident exchange disabled (%s: %s); using the torch exchange"
-                      % (type(exc).__name__, exc), file=sys.stderr, flush=True)
-                self.fast = False
+            self._setup_transport()
 
     # -- device-resident exchange --------------------------------------------------------------------------
     def _plan_device_exchange(self):
@@ -378,10 +376,64 @@ class ShardedState:
         e.ctx.call("gpe_shard_configure", C.byref(plan))
         self.plan = plan
         if self.stage_cpu:
-            # pageable on purpose: torch's pinned-memory allocator would remember the library's stream (an
-            # ExternalStream) past gpe_destroy
-            self.send_host = torch.zeros(so, dtype=torch.int32)
-            self.recv_host = torch.zeros(ro, dtype=torch.int32)
+            # pinned staging buffers: torch's host allocator records the stream they were used on -- the engine's
+            # stream is torch's own (GpeEngine.__init__), so that record stays valid past gpe_destroy
+            self.send_host = torch.zeros(so, dtype=torch.int32).pin_memory()
+            self.recv_host = torch.zeros(ro, dtype=torch.int32).pin_memory()
+
+    def _setup_transport(self):
+        """Who moves the packed segments between the ranks (gpe_shard_exchange, called by gpe_shard_run):
+        "rccl"  -- the library itself: a communicator of its own (gpe_shard_comm_init; the 128-byte id travels over
+                   torch.distributed once), one grouped ncclSend / ncclRecv pair per neighbour on the context's
+                   stream.  The step loop then has no Python in it.  Default when the process group is nccl.
+        "torch" -- a callback into _move_segments (all_to_all_single, or isend / irecv with GPE_SHARD_P2P=1): gloo
+                   rehearsals on a one-GPU box, staged through host memory.
+        A transport that cannot be set up (every rank sees the same error) leaves the run on the next one, and
+        finally on the torch exchange, instead of failing in step 1."""
+        import sys
+        e = self.e
+        want = os.environ.get("GPE_SHARD_TRANSPORT",
+                              "rccl" if (not self.stage_cpu and dist.get_backend(self.group) == "nccl") else "torch")
+        if want == "rccl":
+            try:
+                ident = torch.zeros(L.COMM_ID_BYTES, dtype=torch.uint8)
+                if dist.get_rank(self.group) == 0:
+                    raw = (C.c_uint8 * L.COMM_ID_BYTES)()
+                    L.check(L.load().gpe_comm_unique_id(raw))
+                    ident = torch.tensor(list(raw), dtype=torch.uint8)
+                comm_dev = e.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+                ident = ident.to(comm_dev)
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast(ident, src=src, group=self.group)
+                raw = (C.c_uint8 * L.COMM_ID_BYTES)(*ident.cpu().tolist())
+                torch.cuda.synchronize(e.device)
+                e.ctx.call("gpe_shard_comm_init", raw, self.rank, self.ws)          # collective
+                self.transport = "rccl"
+                return
+            except Exception as exc:                                   # noqa: BLE001 -- any backend error
+                print("[gpe sharded] in-library RCCL transport unavailable (%s: %s); moving the segments with "
+                      "torch.distributed" % (type(exc).__name__, exc), file=sys.stderr, flush=True)
+        try:
+            self._move_segments()                      # rehearse once on the zeroed buffers
+            torch.cuda.synchronize(e.device)
+            self._transport_error = None
+            self._transport_cb = L.SHARD_TRANSPORT_FN(self._transport)   # keep the thunk alive
+            e.ctx.call("gpe_shard_set_transport", self._transport_cb, None)
+            self.transport = "torch"
+        except Exception as exc:                                       # noqa: BLE001
+            print("[gpe sharded] device-resident exchange disabled (%s: %s); using the torch exchange"
+                  % (type(exc).__name__, exc), file=sys.stderr, flush=True)
+            self.fast = False
+
+    def _transport(self, user, d_send, d_recv, stream):
+        """gpe_shard_transport_fn: the library asks for the packed segments to be moved (d_send / d_recv are the
+        buffers of the plan, i.e. self.send_buf / self.recv_buf)."""
+        try:
+            self._move_segments()
+            return 0
+        except Exception as exc:                                       # noqa: BLE001 -- must not unwind into C
+            self._transport_error = exc
+            return 1
 
     def _densest_rank_per_block(self):
         """Particles per owned block on the most crowded rank (a collective: every rank gets the same number, so
@@ -401,7 +453,7 @@ class ShardedState:
             send, recv = self.send_buf[:self.send_words], self.recv_buf[:self.recv_words]
             if self.stage_cpu:                   # gloo rehearsal on a shared GPU: through host memory
                 self.send_host.copy_(send)
-                self.e.sync()
+                self.e.stream.synchronize()
                 send, recv = self.send_host, self.recv_host
             if os.environ.get("GPE_SHARD_P2P") == "1":
                 # the same transfers spelled as explicit point-to-point operations (one isend + one irecv per
@@ -421,14 +473,15 @@ class ShardedState:
             if self.stage_cpu:
                 self.recv_buf[:self.recv_words].copy_(self.recv_host)
 
-    def _fast_update(self, dt, resort):
+    def _fast_update(self, dt, resort, steps=1):
+        """[re-sort, re-cut] + `steps` ordinary steps (the first of them is the re-sort step's own)."""
         e = self.e
         if resort:
             # every particle must sit on its owner before the global indices are assigned
             if not self.fast_active:
                 e.set_counts(self.n_owned, self.n_owned)
                 e.ctx.call("gpe_shard_begin")
-            self._move_segments()
+            e.ctx.call("gpe_shard_exchange")
             e.ctx.call("gpe_shard_unpack")
             self.n_owned, _ = e.shard_counts(leave=True)                  # host sync: re-sort steps only
             e.n_owned = self.n_owned
@@ -443,8 +496,17 @@ class ShardedState:
             e.set_counts(self.n_owned, self.n_owned)
             e.ctx.call("gpe_shard_begin")
             self.fast_active = True
-        self._move_segments()
-        e.ctx.call("gpe_shard_step", float(dt))
+        self._run_steps(dt, steps)
+
+    def _run_steps(self, dt, steps):
+        """`steps` ordinary steps inside the library: exchange (RCCL or the transport callback), unpack, step, pack."""
+        try:
+            self.e.ctx.call("gpe_shard_run", float(dt), int(steps))
+        except L.GpeError:
+            if getattr(self, "_transport_error", None) is not None:
+                exc, self._transport_error = self._transport_error, None
+                raise exc
+            raise
 
     # -- helpers -------------------------------------------------------------------------------------
     def _ensure_capacity(self, need):
@@ -713,8 +775,19 @@ class ShardedState:
         self.stats["steps"] += 1
 
     def run(self, dt, steps, resort_every=0, resort_first=True):
-        for s in range(steps):
-            self.update(dt, resort=(s == 0 and resort_first) or (resort_every and s > 0 and s % resort_every == 0))
+        """state.rs:115-131 `steps` times; re-sorts on the first step (resort_first) and every resort_every steps.
+        With the device-resident exchange all steps between two re-sorts are ONE library call (gpe_shard_run)."""
+        s = 0
+        while s < steps:
+            resort = bool((s == 0 and resort_first) or (resort_every and s > 0 and s % resort_every == 0))
+            if not self.fast:
+                self.update(dt, resort=resort)
+                s += 1
+                continue
+            nxt = steps if not resort_every else min(steps, (s // resort_every + 1) * resort_every)
+            self._fast_update(dt, resort, steps=nxt - s)
+            self.stats["steps"] += nxt - s
+            s = nxt
 
     def owned(self):
         """(gid, pos, prev) of the owned particles as host arrays."""

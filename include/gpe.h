@@ -191,8 +191,14 @@ gpe_status gpe_use_order_keys(gpe_ctx *ctx, int32_t enable);
 /* Cells [cx0..cx1] x [cy0..cy1] contain every resident particle: the native tile grid is cut to it. */
 gpe_status gpe_set_active_cells(gpe_ctx *ctx, int32_t cx0, int32_t cy0, int32_t cx1, int32_t cy1);
 /* The context's hipStream_t, so that a host framework can enqueue its own packing / exchange work in
- * order with the library's kernels (torch.cuda.ExternalStream). */
+ * order with the library's kernels. */
 gpe_status gpe_stream_handle(gpe_ctx *ctx, void **hip_stream);
+/* Run on a stream the CALLER owns (hipStream_t; it must outlive the context or the next gpe_set_stream).  A host
+ * framework that allocates, frees or communicates on the context's stream (torch's caching allocators and
+ * ProcessGroupNCCL remember the stream of every buffer they handle) lends its own stream instead of borrowing
+ * the library's: the library never destroys a borrowed stream.  NULL returns to the library's own stream.
+ * Synchronises the stream in use before switching. */
+gpe_status gpe_set_stream(gpe_ctx *ctx, void *hip_stream);
 /* Re-derive the native pipeline's configuration after the caller changed particles in place. */
 gpe_status gpe_refresh(gpe_ctx *ctx);
 /* For every owned particle whose 8x8-cell block (row-major blocks_x x blocks_y over the world) is owned by
@@ -235,6 +241,32 @@ gpe_status gpe_shard_peek(gpe_ctx *ctx, uint64_t *n_owned, uint64_t *n_total);
 /* Synchronises and returns the device-side counts; leave != 0 also returns the context to host-side counts
  * (owned particles only), e.g. before a Morton re-sort or a download.  Reports exchange errors. */
 gpe_status gpe_shard_counts(gpe_ctx *ctx, uint64_t *n_owned, uint64_t *n_total, int32_t leave);
+
+/* Moving the packed segments between the ranks, inside the library: RCCL point-to-point over xGMI.  One grouped
+ * ncclSend / ncclRecv pair per neighbouring rank on the context's stream (fixed sizes, nothing to wait for on the
+ * host), so a host in any language drives a sharded run with gpe_shard_run alone between two re-sorts.
+ * librccl.so.1 is loaded at the first of these calls (dlopen: a process that already holds RCCL, e.g. under
+ * torch.distributed, shares its copy). */
+#define GPE_COMM_ID_BYTES 128u
+/* ncclGetUniqueId: call on one rank, hand the 128 bytes to every rank (any side channel). */
+gpe_status gpe_comm_unique_id(uint8_t *id128);
+/* ncclCommInitRank on the context's device: collective over the world_size ranks of the decomposition
+ * (rank numbers = gpe_shard_plan.rank / slot_rank).  The communicator belongs to the context. */
+gpe_status gpe_shard_comm_init(gpe_ctx *ctx, const uint8_t *id128, uint32_t rank, uint32_t world_size);
+/* Use a communicator the caller created (ncclComm_t); the caller keeps ownership. */
+gpe_status gpe_shard_comm_attach(gpe_ctx *ctx, void *nccl_comm);
+gpe_status gpe_shard_comm_destroy(gpe_ctx *ctx);
+/* Any other transport (tests: gloo through host memory): fn must enqueue / perform the transfer of every neighbour
+ * segment of d_send into the peers' d_recv in order with hip_stream and return 0.  NULL removes it. */
+typedef int32_t (*gpe_shard_transport_fn)(void *user, const uint32_t *d_send, uint32_t *d_recv, void *hip_stream);
+gpe_status gpe_shard_set_transport(gpe_ctx *ctx, gpe_shard_transport_fn fn, void *user);
+/* Send the segments packed by gpe_shard_begin / gpe_shard_step and receive the neighbours' (communicator or transport). */
+gpe_status gpe_shard_exchange(gpe_ctx *ctx);
+/* `steps` x (gpe_shard_exchange, gpe_shard_step): the step loop of a sharded run between two re-sorts, no host
+ * synchronisation (the host stays at most ~64 steps ahead of the device). */
+gpe_status gpe_shard_run(gpe_ctx *ctx, float dt, uint64_t steps);
+/* Do librccl.so.1 and every entry point used above resolve on this machine?  (No GPU needed.) */
+gpe_status gpe_comm_probe(void);
 
 /* ---- profiling (wgpu_profiler scopes threaded through every reference call) ------------------ */
 typedef struct gpe_timing {

@@ -64,3 +64,13 @@ def test_product_path_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(base, f)).read()
                 assert "gpe_oracle" not in text and "import oracle" not in text and "orc_" not in text, f
+
+
+def test_rccl_transport_links_without_a_gpu(gpe):
+    """The in-library RCCL transport (csrc/gpe_comm.hip) resolves librccl.so.1 and every entry point it calls
+    (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclGroupStart/End, ncclSend, ncclRecv,
+    ncclGetErrorString) on this machine; without a communicator the exchange entry points refuse loudly."""
+    lib = gpe._lib.load()
+    assert lib.gpe_comm_probe() == 0, lib.gpe_last_error(None)
+    assert lib.gpe_shard_exchange(None) == gpe._lib.GPE_ERR_INVALID_ARG
+    assert lib.gpe_shard_run(None, 0.0, 1) == gpe._lib.GPE_ERR_INVALID_ARG

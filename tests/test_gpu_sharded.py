@@ -125,3 +125,36 @@ def test_device_exchange_overflow_is_loud(gpe, tmp_path):
     for r in range(2):
         msg = open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read()
         assert "segment overflowed" in msg, msg
+
+
+def _teardown_worker(rank, ws, port, do_close):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    gpe = importlib.import_module("gpu-physics-engine_amd")
+    sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+    n, world = 40_000, (420.0, 300.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=5)
+    dec = sharded.Decomposition(world, np.float32(0.5) * np.float32(2.2), ws)
+    mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+    eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, gravity=(40.0, 0.0), device=0)
+    st = sharded.ShardedState(eng, dec, rank, device_exchange=True)
+    assert st.fast and st.transport == "torch"
+    st.run(0.05, 8, resort_every=5, resort_first=True)
+    gid, p, q = st.owned()
+    assert len(gid) == st.n_owned and np.isfinite(p).all()
+    if do_close:
+        eng.close()
+    dist.destroy_process_group()
+    # without close(): the context, its torch views and the staging buffers die in whatever order the interpreter
+    # picks as this function returns and the process exits
+
+
+@pytest.mark.parametrize("do_close", [False, True], ids=["no-close", "close"])
+def test_rank_teardown_is_clean(gpe, do_close):
+    """A rank that leaves its worker function (and the process) with or without GpeEngine.close() exits with
+    rc 0: the context runs on a stream torch owns (gpe_set_stream), so nothing torch's allocators remember can
+    name a destroyed stream.  (Round 1: SIGSEGV here when the library's own stream was wrapped in an ExternalStream.)
+    mp.spawn raises ProcessExitedException on any non-zero exit code or signal."""
+    mp.spawn(_teardown_worker, args=(2, _free_port(), do_close), nprocs=2, join=True)
