@@ -805,7 +805,11 @@ __device__ __forceinline__ void resolve_wave_blocked(L &S, const uint32_t b, con
 }
 
 // One tile: returns false when the region exceeds the window's capacity (nothing written).
-template <class L>
+// ORD: a sharded run -- the members of a cell are ordered by A.order_keys[local index] (the particle's index in the
+// unsharded system) instead of by the local index.  A template parameter, not a run-time test: the instantiation
+// of ordinary runs then contains no load of the order keys, and hipcc has no reason to wait for one
+// (s_waitcnt vmcnt(0) in front of every prefetch of a previous position -- the rounds' loads ran one after the other).
+template <bool ORD, class L>
 __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
 {
     constexpr int T = L::TILE;
@@ -869,7 +873,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         if (w > kWindowReport) atomicMax(&A.tile_ctl[kCtlWindowMax], w);
     }
     __syncthreads();
-    const uint32_t P = S.misc[0];
+    const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);   // the same in every lane: keep it scalar
     if (S.misc[1] == 0) return true;                                   // nothing of its own to write
     if constexpr (L::kGlobal) {
         // take a slice of the global spill arena for this tile's particle arrays
@@ -905,12 +909,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         float pr[QMAX];
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
-            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            pid[q] = 0; blk[q] = 0;
-            if (s < P) {
-                blk[q] = S.sblk[s];
-                pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
-            }
+            // Branch-free on purpose: behind `if (s < P)` hipcc merges the loaded value with the default through
+            // register copies that wait for the load (s_waitcnt vmcnt(0) right behind it), so the rounds' loads ran one
+            // after the other -- three dependent global round trips.  Slots beyond P re-read slot P - 1 (a cache hit)
+            // and are discarded by `keep` below.  (P >= 1: the tile has particles of its own.)
+            const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * kNatThreads, P - 1u);
+            blk[q] = S.sblk[s];
+            pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
         }
 #ifdef GPE_TILE_STAMPS
         { uint32_t acc = 0; for (int q = 0; q < QMAX; ++q) acc += pid[q]; asm volatile("" :: "v"(acc)); }
@@ -918,18 +923,15 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #endif
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
-            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            pp[q] = make_float2(0.f, 0.f);
-            pr[q] = 0.f;
-            cc[q] = 0;
-            if (s < P) {
-                pp[q] = A.pos_in[pid[q]];
-                pr[q] = A.radius[pid[q]];
-                cc[q] = A.codes[pid[q]];
-                // sharded run: the member order is the particle's index in the unsharded system; the local
-                // index is looked up again at write-back (P6)
-                if (A.order_keys) pid[q] = A.order_keys[pid[q]];
-            }
+            pp[q] = A.pos_in[pid[q]];
+            pr[q] = A.radius[pid[q]];
+            cc[q] = A.codes[pid[q]];
+        }
+        // sharded run: the member order is the particle's index in the unsharded system; the local index is looked
+        // up again at write-back (P6)
+        if constexpr (ORD) {
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) pid[q] = A.order_keys[pid[q]];
         }
 #ifdef GPE_TILE_STAMPS
         { float acc = 0; for (int q = 0; q < QMAX; ++q) acc += pp[q].x + pr[q]; asm volatile("" :: "v"(acc)); }
@@ -994,7 +996,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // cell window is the looked-up blocks)
     uint32_t PS = P;
     if constexpr (kTrim) {
-        PS = S.misc[3];
+        PS = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[3]);
         if (PS > (uint32_t)(sizeof(S.px) / sizeof(float))) return false;    // more kept particles than the window stages
     }
 
@@ -1044,36 +1046,43 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 
     // The tile's own particles and, when K12 is fused into the write-back, their previous positions: fetched
     // here so that the global round trip runs under the colour passes instead of at the end of the tile.
-    const uint64_t n_owned = A.counts ? (uint64_t)A.counts[0] : A.n_owned;
+    // (a scalar, so that comparing against it waits for no load: the count of a sharded run is read here, once)
+    const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
     constexpr int QOWN = QMAX;                                         // ceil(window capacity / threads)
     uint32_t own_id[QOWN];
     float2 own_prev[QOWN];
     if constexpr (kTrim) {
+        // Branch-free (see P1): every lane loads -- a lane without a particle of the tile reads element 0 -- and
+        // the loads of all rounds are issued before anything uses one of them, so they are in flight together and
+        // nothing waits for them before P6.
+        uint32_t fetch[QOWN];
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
             const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
-            own_id[q] = 0xFFFFFFFFu;
-            own_prev[q] = make_float2(0.f, 0.f);
-            if (s < PS) {
-                const uint32_t hm = S.hm[s];
-                const int home = (int)(hm & 0x7FFu);
-                const int lx = home % RWX, ly = home / RWX;
-                if (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) {
-                    uint32_t id = S.id[s];
-                    asm volatile("" : "+v"(id));                     // keep this an LDS read (no pointer select -> flat load)
-                    if (A.order_keys) {                                // S.id holds the order key: find the block of
-                        const uint32_t raw = hm >> 19;                 // the looked-up slot, re-read the local index
-                        int lo = 0, hi = NBLK;
-                        while (hi - lo > 1) {
-                            const int mid = (lo + hi) >> 1;
-                            if (S.boff[mid] <= raw) lo = mid; else hi = mid;
-                        }
-                        id = A.sorted_ids[S.bstart[lo] + (raw - S.boff[lo])];
-                    }
-                    own_id[q] = id;
-                    if (A.fuse_verlet && id < n_owned) own_prev[q] = A.prev[id];
+            const uint32_t sc = min(s, PS - 1u);                       // PS >= 1: the tile has particles of its own
+            const uint32_t hm = S.hm[sc];
+            const int home = (int)(hm & 0x7FFu);
+            const int lx = home % RWX, ly = home / RWX;
+            const bool own = s < PS && lx >= HX && lx < HX + T && ly >= HY && ly < HY + T;
+            uint32_t id = S.id[sc];
+            asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
+            if constexpr (ORD) {                                       // S.id holds the order key: find the block of
+                const uint32_t raw = hm >> 19;                         // the looked-up slot, re-read the local index
+                int lo = 0, hi = NBLK;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (S.boff[mid] <= raw) lo = mid; else hi = mid;
                 }
+                id = A.sorted_ids[S.bstart[lo] + (raw - S.boff[lo])];
             }
+            own_id[q] = own ? id : 0xFFFFFFFFu;
+            fetch[q] = (own && id < n_owned) ? id : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < QOWN; ++q) {
+            own_prev[q] = make_float2(0.f, 0.f);
+            if (A.fuse_verlet) own_prev[q] = A.prev[fetch[q]];
         }
     }
 
@@ -1173,6 +1182,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #endif
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
+#ifdef GPE_TILE_STAMPS
+        const long long _tw0 = clock64();
+#endif
         const uint32_t ns = S.lcnt[k], group_lanes = S.lcnt[4 + k] * kGroupLanes;
         const uint32_t nw = min(S.lcnt[8 + k], (uint32_t)L::WC);
         const uint32_t single_base = (group_lanes + 63u) & ~63u;      // waves are all-group or all-single
@@ -1206,8 +1218,21 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         }
 #ifdef GPE_TILE_STAMPS
         GPE_STAMP(9 + k);
-#endif
+        {
+            const long long _tw1 = clock64();
+            __syncthreads();
+            const long long _tw2 = clock64();
+            if (A.stamps && lane == 0 && (blockIdx.x & 127u) == 5u) {
+                const int w = tid >> 6;
+                const int cls = ((uint32_t)(w * 64) < group_lanes) ? 0 : ((uint32_t)(w * 64) < work ? 1 : 2);   // groups / singles / idle
+                atomicAdd(&A.stamps[32 + cls], (unsigned long long)(_tw1 - _tw0));
+                atomicAdd(&A.stamps[36 + cls], (unsigned long long)(_tw2 - _tw1));
+                atomicAdd(&A.stamps[40 + cls], 1ull);
+            }
+        }
+#else
         __syncthreads();
+#endif
     }
 #if GPE_P5_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -1241,7 +1266,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         if (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) {
             uint32_t id = S.id[s];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
-            if (A.order_keys) {                                        // S.id holds the order key: find the block of
+            if constexpr (ORD) {                                       // S.id holds the order key: find the block of
                 const uint32_t raw = s;                                // the looked-up slot, re-read the local index
                 int lo = 0, hi = NBLK;
                 while (hi - lo > 1) {
@@ -1270,8 +1295,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 
 // Level 0: one workgroup per 32x32 tile, tiles dealt so that each XCD (blockIdx % 8) works through a
 // contiguous run of tile rows (neighbouring tiles share halo particles in that XCD's L2).
-template <int T, int CAP>
-__global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
+template <int T, int CAP, bool ORD>
+__global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide_dense(CollideArgs A)
 {
     __shared__ TileLds<T, CAP> S;
     const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
@@ -1280,7 +1305,7 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
     const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
     // a tile whose window exceeds the capacity returns early and is listed for k_collide_overflow
-    if (!process_tile(S, A, tx, ty)) {
+    if (!process_tile<ORD>(S, A, tx, ty)) {
         if (threadIdx.x == 0) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
             if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
@@ -1293,6 +1318,7 @@ __global__ __launch_bounds__(kNatThreads) void k_collide_dense(CollideArgs A)
 // indirect dispatch): one work item per 16x16 quarter.  A quarter whose 32x32-cell region is still over capacity
 // is redone by the same workgroup as four 8x8 tiles, and an 8x8 tile whose 24x24-cell window exceeds even that
 // LDS capacity gets its particle arrays from the global spill arena.  One launch, no queue, nothing to wait for.
+template <bool ORD>
 __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs A)
 {
     using Mid = TileLds<kTileMid, kCapMid>;
@@ -1305,15 +1331,15 @@ __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs
     for (uint32_t i = blockIdx.x; i < work; i += gridDim.x) {
         const uint32_t parent = A.overflow1[i >> 2];
         const int tx = (int)((parent & 0xFFFFu) * 2u + (i & 1u)), ty = (int)((parent >> 16) * 2u + ((i >> 1) & 1u));
-        const bool done = process_tile(u.mid, A, tx, ty);
+        const bool done = process_tile<ORD>(u.mid, A, tx, ty);
         __syncthreads();                                               // the union's views alias each other
         if (done) continue;
         for (int sub = 0; sub < 4; ++sub) {
             const int sx = tx * 2 + (sub & 1), sy = ty * 2 + (sub >> 1);
-            bool ok = process_tile(u.small, A, sx, sy);
+            bool ok = process_tile<ORD>(u.small, A, sx, sy);
             __syncthreads();
             if (ok) continue;
-            ok = process_tile(u.spill, A, sx, sy);
+            ok = process_tile<ORD>(u.spill, A, sx, sy);
             __syncthreads();
             if (ok) continue;
             // the spill arena is exhausted: flag it (gpe_sync / gpe_download report the error) and pass the
@@ -1579,17 +1605,21 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.stamps = nullptr;
 #ifdef GPE_TILE_STAMPS
     static unsigned long long *g_stamps = nullptr;
-    if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 32 * 8); (void)hipMemset(g_stamps, 0, 32 * 8); }
+    if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 64 * 8); (void)hipMemset(g_stamps, 0, 64 * 8); }
     A.stamps = g_stamps;
     static int g_calls = 0;
     if (++g_calls % 20 == 0) {
-        unsigned long long h[32];
+        unsigned long long h[64];
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemcpy(h, g_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        for (int cls = 0; cls < 3; ++cls)
+            fprintf(stderr, "[P5 waves] %s: busy %.0f  barrier wait %.0f cycles per colour pass (%llu wave-passes)\n",
+                    cls == 0 ? "group waves" : cls == 1 ? "single waves" : "idle waves", h[40 + cls] ? (double)h[32 + cls] / h[40 + cls] : 0.0,
+                    h[40 + cls] ? (double)h[36 + cls] / h[40 + cls] : 0.0, h[40 + cls]);
         fprintf(stderr, "[tile stamps] n=%llu", (unsigned long long)c->n);
         for (int i = 0; i < 14; ++i) fprintf(stderr, "  P%d %.0f", i, h[16 + i] ? (double)h[i] / (double)h[16 + i] : 0.0);
         fprintf(stderr, "  (tiles %llu)\n", h[16 + 6]);
-        (void)hipMemset(g_stamps, 0, 32 * 8);
+        (void)hipMemset(g_stamps, 0, 64 * 8);
     }
 #endif
     int32_t cx0 = 0, cy0 = 0, cx1 = N.gx - 1, cy1 = N.gy - 1;
@@ -1606,7 +1636,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
         const uint32_t grid = ((total + 7u) / 8u) * 8u;
-        hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        if (A.order_keys)
+            hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        else
+            hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
     {
@@ -1614,7 +1647,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // running this launch on a second stream beside the dense one -- the stream fork/join costs ~8 us per step,
         // more than the normally empty launch it hides; it only pays in clustered scenes.)
         Scope s(c, "native/collide-dense-regions");
-        hipLaunchKernelGGL(k_collide_overflow, dim3(1024), dim3(kNatThreads), 0, c->stream, A);
+        if (A.order_keys)
+            hipLaunchKernelGGL(k_collide_overflow<true>, dim3(1024), dim3(kNatThreads), 0, c->stream, A);
+        else
+            hipLaunchKernelGGL(k_collide_overflow<false>, dim3(1024), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
     return GPE_OK;

@@ -17,6 +17,7 @@ State composes them (state.rs:34-70).  Errors surface as GpeError (the reference
 numpy is used only to hold host arrays; every call goes through ctypes to libgpe.so.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -54,10 +55,9 @@ class Context:
     def __del__(self):
         # not during interpreter shutdown: the HIP runtime may already have been torn down by then, and the
         # process is about to release everything anyway
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
         try:
+            if sys is None or sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass
