@@ -95,6 +95,7 @@ static gpe_status dev_alloc(gpe_ctx *c, T **p, uint64_t count)
 {
     *p = nullptr;
     hipError_t e = hipMalloc((void **)p, std::max<uint64_t>(count, 4) * sizeof(T) + 64);
+    if (e != hipSuccess) (void)hipGetLastError();   // the failure is reported here: do not leave it for the next launch check
     if (e == hipErrorOutOfMemory) return fail(c, GPE_ERR_OOM, "hipMalloc: out of device memory");
     if (e != hipSuccess) return fail(c, GPE_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorName(e));
     return GPE_OK;
@@ -185,51 +186,88 @@ static gpe_status init_index_buffers(gpe_ctx *c, uint64_t lo, uint64_t hi)
 
 // Reallocate every particle-count-dependent buffer for `cap` particles, keeping the contents of the
 // first c->n (GpuBuffer::push grows x2 with a device copy, utils/gpu_buffer.rs:49-87).  Synchronises.
-static gpe_status grow_particle_buffers(gpe_ctx *c, uint64_t cap)
+// Transactional: the new set is allocated beside the old one and takes its place only when every allocation and
+// copy has succeeded; on failure the new set is freed and the context is exactly as before.
+struct ParticleBufferSet {
+    float2 *pos = nullptr, *prev = nullptr, *pos_copy = nullptr, *prev_copy = nullptr;
+    float *radius = nullptr, *radius_copy = nullptr;
+    uint32_t *home_cell_ids = nullptr, *particle_ids = nullptr, *cell_ids = nullptr, *object_ids = nullptr,
+             *chunk_obj_count = nullptr, *collision_cells = nullptr, *indirect_args = nullptr, *order_keys = nullptr;
+    uint64_t cap = 0;
+};
+static ParticleBufferSet take_buffers(gpe_ctx *c)
 {
-    struct Old {
-        float2 *pos, *prev, *pos_copy, *prev_copy;
-        float *radius, *radius_copy;
-        uint32_t *home_cell_ids, *particle_ids, *cell_ids, *object_ids, *chunk_obj_count, *collision_cells,
-            *indirect_args, *order_keys;
-    } old = {c->pos, c->prev, c->pos_copy, c->prev_copy, c->radius, c->radius_copy, c->home_cell_ids,
-             c->particle_ids, c->cell_ids, c->object_ids, c->chunk_obj_count, c->collision_cells,
-             c->indirect_args, c->order_keys};
-    const uint64_t old_n = c->n;
-    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    ParticleBufferSet b;
+    b.pos = c->pos; b.prev = c->prev; b.pos_copy = c->pos_copy; b.prev_copy = c->prev_copy;
+    b.radius = c->radius; b.radius_copy = c->radius_copy;
+    b.home_cell_ids = c->home_cell_ids; b.particle_ids = c->particle_ids; b.cell_ids = c->cell_ids;
+    b.object_ids = c->object_ids; b.chunk_obj_count = c->chunk_obj_count; b.collision_cells = c->collision_cells;
+    b.indirect_args = c->indirect_args; b.order_keys = c->order_keys;
+    b.cap = c->cap;
     c->pos = c->prev = c->pos_copy = c->prev_copy = nullptr;
     c->radius = c->radius_copy = nullptr;
     c->home_cell_ids = c->particle_ids = c->cell_ids = c->object_ids = nullptr;
     c->chunk_obj_count = c->collision_cells = c->indirect_args = c->order_keys = nullptr;
-    GPE_TRY(alloc_particle_buffers(c, cap));
-    if (old.pos && old_n) {
+    c->cap = 0;
+    return b;
+}
+static void put_buffers(gpe_ctx *c, const ParticleBufferSet &b)
+{
+    c->pos = b.pos; c->prev = b.prev; c->pos_copy = b.pos_copy; c->prev_copy = b.prev_copy;
+    c->radius = b.radius; c->radius_copy = b.radius_copy;
+    c->home_cell_ids = b.home_cell_ids; c->particle_ids = b.particle_ids; c->cell_ids = b.cell_ids;
+    c->object_ids = b.object_ids; c->chunk_obj_count = b.chunk_obj_count; c->collision_cells = b.collision_cells;
+    c->indirect_args = b.indirect_args; c->order_keys = b.order_keys;
+    c->cap = b.cap;
+}
+
+static gpe_status copy_into_new_buffers(gpe_ctx *c, const ParticleBufferSet &old, uint64_t old_n)
+{
+    if (!old.pos || old_n == 0) return GPE_OK;
 #define GPE_COPY_OLD(field, count)                                                                     \
-        GPE_HIP(c, hipMemcpyAsync(c->field, old.field, (count) * sizeof(*c->field), hipMemcpyDeviceToDevice, c->stream))
-        GPE_COPY_OLD(pos, old_n); GPE_COPY_OLD(prev, old_n); GPE_COPY_OLD(radius, old_n);
-        GPE_COPY_OLD(home_cell_ids, old_n); GPE_COPY_OLD(particle_ids, old_n);
-        GPE_COPY_OLD(cell_ids, 4 * old_n); GPE_COPY_OLD(object_ids, 4 * old_n);
-        GPE_COPY_OLD(chunk_obj_count, old_n); GPE_COPY_OLD(collision_cells, 4 * old_n);
-        GPE_COPY_OLD(indirect_args, 3);
-        if (old.order_keys) GPE_COPY_OLD(order_keys, old_n);
+    GPE_HIP(c, hipMemcpyAsync(c->field, old.field, (count) * sizeof(*c->field), hipMemcpyDeviceToDevice, c->stream))
+    GPE_COPY_OLD(pos, old_n); GPE_COPY_OLD(prev, old_n); GPE_COPY_OLD(radius, old_n);
+    GPE_COPY_OLD(home_cell_ids, old_n); GPE_COPY_OLD(particle_ids, old_n);
+    GPE_COPY_OLD(cell_ids, 4 * old_n); GPE_COPY_OLD(object_ids, 4 * old_n);
+    GPE_COPY_OLD(chunk_obj_count, old_n); GPE_COPY_OLD(collision_cells, 4 * old_n);
+    GPE_COPY_OLD(indirect_args, 3);
+    if (old.order_keys) GPE_COPY_OLD(order_keys, old_n);
 #undef GPE_COPY_OLD
-    }
     GPE_HIP(c, hipStreamSynchronize(c->stream));
-    float2 *fp[] = {old.pos, old.prev, old.pos_copy, old.prev_copy};
-    for (float2 *p : fp) if (p) (void)hipFree(p);
-    float *ff[] = {old.radius, old.radius_copy};
-    for (float *p : ff) if (p) (void)hipFree(p);
-    uint32_t *fu[] = {old.home_cell_ids, old.particle_ids, old.cell_ids, old.object_ids, old.chunk_obj_count,
-                      old.collision_cells, old.indirect_args, old.order_keys};
-    for (uint32_t *p : fu) if (p) (void)hipFree(p);
+    return GPE_OK;
+}
+
+static gpe_status grow_particle_buffers(gpe_ctx *c, uint64_t cap)
+{
+    const uint64_t old_n = c->n;
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    const ParticleBufferSet old = take_buffers(c);                     // the context now holds no particle buffer
+    gpe_status st = alloc_particle_buffers(c, cap);
+    if (st == GPE_OK) st = copy_into_new_buffers(c, old, old_n);
+    if (st != GPE_OK) {
+        const std::string why = c->last_error;
+        free_particle_buffers(c);                                      // whatever part of the new set exists
+        put_buffers(c, old);                                           // the context is as it was
+        c->last_error = why;
+        return st;
+    }
+    float2 *f2[] = {old.pos, old.prev, old.pos_copy, old.prev_copy};
+    for (float2 *p : f2) if (p) (void)hipFree(p);
+    float *f1[] = {old.radius, old.radius_copy};
+    for (float *p : f1) if (p) (void)hipFree(p);
+    uint32_t *u[] = {old.home_cell_ids, old.particle_ids, old.cell_ids, old.object_ids, old.chunk_obj_count,
+                     old.collision_cells, old.indirect_args, old.order_keys};
+    for (uint32_t *p : u) if (p) (void)hipFree(p);
     return GPE_OK;
 }
 
 static float max_abs_radius(const float *radius, uint64_t n, float start)
 {
-    // particle_system.rs:51: the radius of largest magnitude (the element itself, sign kept)
+    // particle_system.rs:51: the radius of largest magnitude (the element itself, sign kept; of several elements
+    // of that magnitude the last one -- Rust's max_by -- which decides the sign of cell_size for radii like [2, -2])
     float best = start;
     for (uint64_t i = 0; i < n; ++i)
-        if (!(fabsf(radius[i]) <= fabsf(best))) best = radius[i];
+        if (!(fabsf(radius[i]) < fabsf(best))) best = radius[i];      // ties: the LAST element, as Iterator::max_by returns
     return best;
 }
 

@@ -239,7 +239,8 @@ struct OnesweepWorkspace {
 
 // Native (N-key sort + LDS cell windows) pipeline state
 struct NativeState {
-    bool eligible = false;           // every particle inside the world box, grid small enough
+    bool eligible = false;           // every particle inside the world box, grid small enough, windows not over-dense
+    bool in_box = false;             // the configuration-time box check passed (density is the only possible obstacle)
     int32_t gx = 0, gy = 0;          // home cell columns / rows: cx in [0,gx), cy in [0,gy)
     int passes = 4;                  // radix passes needed for morton(gx-1, gy-1)
     uint32_t table_entries = 0;      // 8x8-cell block table length
@@ -257,7 +258,7 @@ struct NativeState {
     void *arena = nullptr;           // global spill arena for those tiles' particle arrays (37 B per slot)
     uint64_t arena_cap = 0;          // slots
     bool force = false;              // GPE_NATIVE_FORCE=1 (tests): no hand-over to the compat kernels
-    uint32_t *host_stat = nullptr;   // pinned: [0] last reported max 24x24-cell window population
+    uint32_t *host_stat = nullptr;   // pinned, 16 words (k_native.hip kStat*): window maximum, arena use, probe answer, overflow tiles
     uint32_t window_max = 0;         // the same, measured synchronously at configuration time
     bool dense_hold = false;         // left the native path because windows were filling up
     uint32_t steps_since_check = 0;
@@ -362,10 +363,12 @@ gpe_status fail(gpe_ctx *ctx, gpe_status code, const std::string &msg);
 #define GPE_HIP(ctx, expr)                                                                      \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess)                                                                   \
-            return gpe::fail((ctx), GPE_ERR_HIP,                                                \
+        if (_e != hipSuccess) {                                                                 \
+            (void)hipGetLastError(); /* reported here: not left for the next launch check */    \
+            return gpe::fail((ctx), _e == hipErrorOutOfMemory ? GPE_ERR_OOM : GPE_ERR_HIP,      \
                              std::string(#expr) + ": " + hipGetErrorName(_e) + " (" +           \
                                  hipGetErrorString(_e) + ")");                                  \
+        }                                                                                       \
     } while (0)
 #define GPE_TRY(expr)                                                                           \
     do {                                                                                        \

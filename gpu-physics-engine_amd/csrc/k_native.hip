@@ -86,7 +86,13 @@ constexpr int kCtlArena = 3;                   // particles handed out of the gl
 constexpr int kCtlHashDone = 4;                // hash workgroups that have flushed their histograms
 constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every step
 constexpr int kCtlError = 8;                   // sticky
-constexpr uint64_t kArenaBytesPerSlot = 37;    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
+// pinned host words the kernels report to (read by the step policy with a lag of the steps in flight)
+constexpr int kStatWindowMax = 0;              // largest 24x24-cell window population of the last native step
+constexpr int kStatArena = 1;                  // spill-arena slots handed out by the last native step
+constexpr int kStatProbe = 2;                  // window population measured by the last asynchronous probe + 1 (0: none yet)
+constexpr int kStatOverflow = 3;               // 32x32 tiles over capacity in the last native step
+constexpr uint64_t kArenaBytesPerSlot = 37;
+constexpr uint64_t kArenaMaxSlots = 1ull << 30; // the arena's slot numbers are 32 bit; 40 GB of the 288 GB    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
 #ifndef GPE_CAP_MAIN
 #define GPE_CAP_MAIN 1192
@@ -177,7 +183,11 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         table2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);      // (first, one past last) = (max, 0): empty
     if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords && threadIdx.x != kCtlHashDone) {
-        if (threadIdx.x == kCtlWindowMax && host_stat) host_stat[0] = tile_ctl[kCtlWindowMax];
+        if (host_stat) {                                               // last step's statistics (kStat*), lagged
+            if (threadIdx.x == kCtlWindowMax) host_stat[kStatWindowMax] = tile_ctl[kCtlWindowMax];
+            if (threadIdx.x == kCtlArena) host_stat[kStatArena] = tile_ctl[kCtlArena];
+            if (threadIdx.x == kCtlOverflow1) host_stat[kStatOverflow] = tile_ctl[kCtlOverflow1];
+        }
         tile_ctl[threadIdx.x] = 0;
     }
     __syncthreads();
@@ -285,6 +295,15 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_window_max(const uint2 
     }
     for (int d = 32; d >= 1; d >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, d, 64));
     if (lane_id() == 0 && best) atomicMax(out_max, best);
+}
+
+// the asynchronous probe's last link: the measured maximum (+ 1, so that 0 means "no answer yet") goes to the host
+__global__ void k_native_publish_probe(uint32_t *__restrict__ tile_ctl, uint32_t *__restrict__ host_stat)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        __hip_atomic_store(&host_stat[kStatProbe], tile_ctl[kCtlWindowMax] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        tile_ctl[kCtlWindowMax] = 0;
+    }
 }
 
 // every particle inside the cell box?  (configuration-time check, not on the step path)
@@ -1387,6 +1406,8 @@ void native_release(gpe_ctx *c)
     N = NativeState();
 }
 
+static gpe_status arena_reserve(gpe_ctx *c, uint64_t want);
+
 // hash -> sort -> block table.  *sorted_ids receives the particle ids in Morton order of their home cell.
 static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
 {
@@ -1429,6 +1450,8 @@ gpe_status native_configure(gpe_ctx *c)
 {
     NativeState &N = c->native;
     N.eligible = false;
+    N.in_box = false;
+    N.dense_hold = false;
     N.steps_since_check = 0;
     if (c->n == 0 || !(c->cell_size > 0.0f)) return GPE_OK;
     // largest home coordinate a clamped particle can take: floor(world / cell_size)
@@ -1491,16 +1514,11 @@ gpe_status native_configure(gpe_ctx *c)
         // spill arena: every particle can be staged by the 9 windows around it, but a scene that dense has
         // left the native path long before (native_should_run); one slot per particle, 1 M .. 32 M slots
         const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, 1ull << 20), 32ull << 20);
-        if (N.arena_cap < want) {
-            if (N.arena) GPE_HIP(c, hipFree(N.arena));
-            N.arena = nullptr; N.arena_cap = 0;
-            GPE_HIP(c, hipMalloc(&N.arena, want * kArenaBytesPerSlot + 256));
-            N.arena_cap = want;
-        }
+        GPE_TRY(arena_reserve(c, std::max<uint64_t>(want, N.arena_cap)));
     }
     if (!N.tile_ctl) GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, 64));
     if (!N.host_stat) GPE_HIP(c, hipHostMalloc((void **)&N.host_stat, 64, hipHostMallocDefault));
-    N.host_stat[0] = 0;
+    memset(N.host_stat, 0, 64);
     GPE_TRY(onesweep_reserve(c, c->cap));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
     hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kStreamBlock), 0, c->stream, c->pos, c->n,
@@ -1512,6 +1530,7 @@ gpe_status native_configure(gpe_ctx *c)
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));         // the check's verdict is not a step error
     if (flag != 0) return GPE_OK;                                      // a particle outside the box: compat kernels
+    N.in_box = true;
     // window population of the current state
     const bool prof = c->profiling;
     c->profiling = false;
@@ -1535,27 +1554,83 @@ gpe_status native_configure(gpe_ctx *c)
     return GPE_OK;
 }
 
-// Should this step take the native kernels?  The tiles report the step's largest 24x24-cell window
-// population to pinned host memory (asynchronously, so the value lags by the steps still in flight;
-// gpe_run bounds that).  Above 3/4 of the smallest window's capacity the context leaves the native path
-// before a window can overfill, and re-evaluates (synchronously) every 256 steps.
+// The spill arena: every particle of a dense region can be staged by the 9 windows around it.  One slot per
+// particle to start with (1 M .. 32 M slots); native_should_run doubles it when a step used more than half.
+static gpe_status arena_reserve(gpe_ctx *c, uint64_t want)
+{
+    NativeState &N = c->native;
+    if (N.arena_cap >= want) return GPE_OK;
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    if (N.arena) GPE_HIP(c, hipFree(N.arena));
+    N.arena = nullptr; N.arena_cap = 0;
+    hipError_t e = hipMalloc(&N.arena, want * kArenaBytesPerSlot + 256);
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (e == hipErrorOutOfMemory) return fail(c, GPE_ERR_OOM, "native collide: out of device memory for the spill arena");
+    if (e != hipSuccess) return fail(c, GPE_ERR_HIP, std::string("hipMalloc (spill arena): ") + hipGetErrorName(e));
+    N.arena_cap = want;
+    return GPE_OK;
+}
+
+// While a dense scene is held on the compat kernels: measure the window population of the current state WITHOUT a
+// host synchronisation -- hash + sort + window maximum are enqueued, the answer lands in pinned memory and is read
+// by a later call.  (Round 1 re-ran native_configure here: two stream synchronisations and possibly a reallocation
+// inside gpe_run every 256 steps.)
+static gpe_status native_probe_async(gpe_ctx *c)
+{
+    NativeState &N = c->native;
+    const bool prof = c->profiling;
+    c->profiling = false;
+    uint32_t *ids = nullptr;
+    const gpe_status st = native_prepare_step(c, &ids);
+    c->profiling = prof;
+    GPE_TRY(st);
+    hipLaunchKernelGGL(k_native_window_max, dim3(stream_grid(N.table_entries)), dim3(kStreamBlock), 0, c->stream,
+                       N.block_table, N.table_entries, N.blocks_x, N.blocks_y, N.tile_ctl + kCtlWindowMax);
+    hipLaunchKernelGGL(k_native_publish_probe, dim3(1), dim3(64), 0, c->stream, N.tile_ctl, N.host_stat);
+    GPE_HIP(c, hipGetLastError());
+    return GPE_OK;
+}
+
+// Should this step take the native kernels?  The tiles report the step's largest 24x24-cell window population and
+// the spill-arena slots they used to pinned host memory (asynchronously, so the values lag by the steps still in
+// flight; gpe_run bounds that).  Windows above the handover population (one-lane O(n^2) cells that overlapping
+// windows would repeat) send the context to the compat kernels -- unless the run needs the native ones (order keys
+// of a sharded run: there the dense windows keep going through the spill arena).  A held context probes the state
+// every 256 steps without synchronising and returns when the windows have thinned out.  Nothing here frees or
+// allocates on ordinary steps; the arena grows (one synchronisation) when a step has used more than half of it.
 bool native_should_run(gpe_ctx *c)
 {
     NativeState &N = c->native;
     if (c->cfg.mode != GPE_MODE_NATIVE) return false;
+    const bool must_stay = N.force || c->use_order_keys;
+    if (!N.eligible && must_stay && N.in_box) { N.eligible = true; N.dense_hold = false; }   // density alone never stops such a run
     if (N.eligible) {
-        if (!N.force && N.host_stat && N.host_stat[0] > kWindowHandover) {
+        if (N.host_stat && (uint64_t)N.host_stat[kStatArena] * 2 > N.arena_cap && N.arena_cap < kArenaMaxSlots) {
+            if (arena_reserve(c, std::min<uint64_t>(N.arena_cap * 2, kArenaMaxSlots)) != GPE_OK) return false;
+            N.host_stat[kStatArena] = 0;
+        }
+        if (!must_stay && N.host_stat && N.host_stat[kStatWindowMax] > kWindowHandover) {
             N.eligible = false;
             N.dense_hold = true;
             N.steps_since_check = 0;
+            N.host_stat[kStatProbe] = 0;
         }
         return N.eligible;
     }
-    if (N.dense_hold && ++N.steps_since_check >= 256) {
-        N.dense_hold = false;
-        if (native_configure(c) != GPE_OK) return false;
-        if (!N.eligible) N.dense_hold = true;
-        return N.eligible;
+    if (N.dense_hold) {
+        const uint32_t probe = N.host_stat ? N.host_stat[kStatProbe] : 0u;
+        if (probe != 0 && probe - 1u <= kWindowHandover * 3 / 4) {    // the last probe found the windows thin again
+            N.dense_hold = false;
+            N.eligible = true;
+            N.host_stat[kStatWindowMax] = probe - 1u;
+            N.host_stat[kStatProbe] = 0;
+            return true;
+        }
+        if (++N.steps_since_check >= 256) {
+            N.steps_since_check = 0;
+            N.host_stat[kStatProbe] = 0;
+            (void)native_probe_async(c);
+        }
     }
     return false;
 }

@@ -44,7 +44,8 @@ enum {
     GPE_ERR_NO_DEVICE = -6     /* no gfx950 device visible: there is NO CPU fallback         */
 };
 
-/* Which kernels gpe_step() runs.  Both produce identical positions (tests/test_parity_gpu.py).
+/* Which kernels gpe_step() runs.  Both produce identical positions
+ * (tests/test_gpu_native.py::test_native_equals_compat_1m, _100m; each against the oracle: test_gpu_parity_step.py).
  * COMPAT materialises the reference's own intermediate buffers every step (4N (cell,object)
  * pairs, chunk counts, collision-cell list) -- needed for bit-exact comparison with the
  * reference tests.  NATIVE is the MI355X design: N-key sort + LDS-staged cell windows. */

@@ -315,3 +315,24 @@ def test_config1_1m_particles_match_oracle_directly(gpe, oracle):
         st.close(); sim.close()
     finally:
         oracle.set_threads(1)
+
+
+def test_gravity_soak_piles_up_without_error(gpe):
+    """Gravity on, run long enough for the cloud to fall, pile up and be crushed at the floor (cells of dozens of
+    members, windows beyond the LDS capacity: sub-tile windows, whole-wave cells, spill arena, possibly the handover to
+    the compat kernels and the way back).  No error at any point, and the same bits as a compat-only run."""
+    n = 2_000_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x50A1)
+    g = (0.0, -9.81)
+    a = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_NATIVE)
+    b = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_COMPAT)
+    done = 0
+    for chunk in (600, 600, 600):
+        a.run(1 / 60, chunk, resort_every=240, resort_first=(done == 0))
+        b.run(1 / 60, chunk, resort_every=240, resort_first=(done == 0))
+        done += chunk
+        a.ctx.sync()                                   # reports any sticky device error
+        assert np.array_equal(a.positions(), b.positions()), "after %d steps" % done
+    assert np.isfinite(a.positions()).all()
+    a.close(); b.close()

@@ -190,3 +190,45 @@ def test_full_size_1m_properties(gpe, oracle):
     p = st.positions()
     assert (p[:, 0] >= 0.5).all() and (p[:, 0] <= world[0] - 0.5).all()          # wall clamp
     st.close(); sim.close()
+
+
+def test_failed_growth_leaves_the_context_intact(gpe, oracle):
+    """gpe_reserve for more memory than the device has: GPE_ERR_OOM, and the context is exactly as before -- the new
+    buffer set is allocated beside the old one and replaces it only when every allocation and copy has succeeded
+    (round 1 nulled the pointers first: a failed growth lost the particles and the next step dereferenced NULL)."""
+    n = 5000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=77)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    st.update(1 / 60, resort=True); sim.step(1 / 60, resort=True)
+    import ctypes as C
+    blocker = C.c_void_p()
+    st.ctx.call("gpe_buffer_alloc", 262 << 30, C.byref(blocker))       # leaves ~25 of the 288 GB free
+    try:
+        with pytest.raises(gpe.GpeError) as e:
+            st.ctx.call("gpe_reserve", 400_000_000)                     # ~170 B per particle = 68 GB
+        assert e.value.status == gpe._lib.GPE_ERR_OOM
+    finally:
+        st.ctx.call("gpe_buffer_free", blocker)
+    for s in range(3):
+        st.update(1 / 60, resort=(s == 1)); sim.step(1 / 60, resort=(s == 1))
+    assert np.array_equal(st.positions(), sim.pos)
+    st.ctx.sync()
+    st.close(); sim.close()
+
+
+def test_max_radius_takes_the_last_of_equal_magnitudes(gpe):
+    """particle_system.rs:51 uses Iterator::max_by, which returns the LAST maximum: radii [2, -2] give max_radius -2
+    (and a negative cell size), [-2, 2] give 2."""
+    import ctypes as C
+    pos = np.array([[5.0, 5.0], [9.0, 9.0]], np.float32)
+    for radii, want in (([2.0, -2.0], -2.0), ([-2.0, 2.0], 2.0), ([1.0, 3.0, -3.0, 2.0], -3.0)):
+        p = np.zeros((len(radii), 2), np.float32) + 5.0
+        ctx = gpe.Context(world=(100.0, 100.0))
+        r = np.array(radii, np.float32)
+        ctx.call("gpe_set_particles", p.ctypes.data_as(C.c_void_p), None, r.ctypes.data_as(C.c_void_p), len(radii))
+        out = C.c_float()
+        ctx.call("gpe_max_radius", C.byref(out))
+        assert out.value == want, (radii, out.value)
+        ctx.close()

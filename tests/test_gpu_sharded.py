@@ -158,3 +158,63 @@ def test_rank_teardown_is_clean(gpe, do_close):
     name a destroyed stream.  (Round 1: SIGSEGV here when the library's own stream was wrapped in an ExternalStream.)
     mp.spawn raises ProcessExitedException on any non-zero exit code or signal."""
     mp.spawn(_teardown_worker, args=(2, _free_port(), do_close), nprocs=2, join=True)
+
+
+def _blob_worker(rank, ws, port, n, world, mouse, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=11)
+        dec = sharded.Decomposition(world, np.float32(0.5) * np.float32(2.2), ws)
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, device=0)
+        eng.ctx.call("gpe_set_mouse", 1, float(mouse[0]), float(mouse[1]))
+        st = sharded.ShardedState(eng, dec, rank, device_exchange=True)
+        for s0 in range(0, steps, 6):                     # the same schedule as the reference: re-sort every 60 steps
+            st.run(1 / 60, 6, resort_every=0, resort_first=(s0 % 60 == 0))
+        gid, p, q = st.owned()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=gid, pos=p, prev=q)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_blob_crosses_the_handover_threshold(gpe, tmp_path):
+    """Mouse attraction packs the cloud into a blob on the boundary between two ranks: 24x24-cell windows pass the
+    population at which a single-device run hands over to the compat kernels (4096).  A sharded run cannot hand over
+    (the compat kernels know no order keys) -- round 1 aborted with GPE_ERR_UNSUPPORTED here; now its dense windows
+    keep going through the sub-tile windows and the spill arena.  Same bits as the single-device run, which does
+    hand over."""
+    n, world = 100_000, (420.0, 300.0)
+    mouse = (210.0, 150.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=11)
+    ref = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    ref.particles.mouse_click_callback(True, mouse)
+
+    def densest(p):                                        # particles in the fullest 26 x 26 unit window (~24x24 cells)
+        h, _, _ = np.histogram2d(p[:, 0], p[:, 1], bins=(int(world[0] // 13), int(world[1] // 13)))
+        return (h[:-1, :-1] + h[1:, :-1] + h[:-1, 1:] + h[1:, 1:]).max()
+
+    # run the single-device reference until the blob is denser than the handover population, and a little beyond
+    steps, dense = 0, 0
+    while steps < 150 and dense <= 4200:
+        ref.run(1 / 60, 6, resort_every=0, resort_first=(steps % 60 == 0))
+        steps += 6
+        dense = densest(ref.positions())
+    assert dense > 4096, "the blob never got dense enough (%d)" % dense
+    want_pos, want_prev = ref.positions(), ref.previous_positions()
+    ref.close()
+    mp.spawn(_blob_worker, args=(2, _free_port(), n, world, mouse, steps, str(tmp_path)), nprocs=2, join=True)
+    gids, poss, prevs = [], [], []
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        gids.append(d["gid"]); poss.append(d["pos"]); prevs.append(d["prev"])
+    gid = np.concatenate(gids)
+    assert np.array_equal(np.sort(gid), np.arange(n))
+    order = np.argsort(gid)
+    assert np.array_equal(np.concatenate(poss)[order], want_pos)
+    assert np.array_equal(np.concatenate(prevs)[order], want_prev)
