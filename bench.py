@@ -336,7 +336,7 @@ def extra_entry(name, run, n_per_gpu, ngpu, steps, mode, resort_note):
     }
 
 
-def run_soak(gpe, torch, n, mode, device, total=3000, window=100, marks=(500, 1500, 2500)):
+def run_soak(gpe, torch, n, mode, device, total=3000, window=100, marks=(250, 500, 750, 1000, 1250, 1500, 2000, 2500)):
     """The 100M gravity-on scene does not stay a fresh cloud: it falls, piles up and is crushed.  Steps/s over
     `window` steps around each mark, so the steady state is reported next to the fresh-cloud figure."""
     import numpy as np

@@ -110,7 +110,7 @@ constexpr uint32_t kWindowReport = 512;     // tiles report windows above this p
 // attraction: thousands per cell) are one-lane O(n^2) work that the overlapping windows would repeat: those leave
 // the native path.
 #ifndef GPE_WINDOW_HANDOVER
-#define GPE_WINDOW_HANDOVER 4096
+#define GPE_WINDOW_HANDOVER 16384
 #endif
 constexpr uint32_t kWindowHandover = GPE_WINDOW_HANDOVER;              // above it the context leaves the native path
 constexpr uint32_t kWindowEligible = GPE_WINDOW_HANDOVER * 3 / 2;      // a scene whose windows exceed this never enters it
