@@ -465,7 +465,7 @@ def main():
             extra = "  %.0f GB/s algorithmic" % roofs[name]["GBps"]
         log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
     dom = max(roofs.items(), key=lambda kv: kv[1]["total_ms"]) if roofs else None
-    traffic, traffic_note = None, None
+    traffic, traffic_note, tj = None, None, {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if dom and os.path.exists(tpath):
         try:
@@ -479,6 +479,22 @@ def main():
                 log("warning: " + traffic_note)
         except Exception:
             traffic = None
+    valu = None
+    try:
+        sq = tj.get("sq", {}).get(dom[0], {}).get(str(n)) if dom else None
+        if sq and sq.get("GRBM_GUI_ACTIVE"):
+            cycles = sq["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
+            per_simd = sq["SQ_INSTS_VALU"] / 1024.0                   # 256 CUs x 4 SIMDs
+            # one SIMD issues a wave64 VALU instruction per ~2.2 cycles (fma / integer add) to ~4.1 cycles (compare +
+            # select), measured with 4-8 waves per SIMD: profiles/r02/valu_issue_probe.txt
+            valu = {"valu_wave_insts_per_launch": sq["SQ_INSTS_VALU"], "kernel_cycles": round(cycles),
+                    "issue_busy_frac_at_2.2_cycles": round(per_simd * 2.2 / cycles, 3),
+                    "issue_busy_frac_at_4.1_cycles": round(per_simd * 4.1 / cycles, 3),
+                    "lanes_active_per_valu_inst": round(sq.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * max(1, sq.get("SQ_ACTIVE_INST_VALU", 1))), 3),
+                    "wave_cycles_waiting_frac": round(sq.get("SQ_WAIT_ANY", 0) / max(1, sq.get("SQ_WAVE_CYCLES", 1)), 3),
+                    "source": "SQ counters recorded in profiles/traffic.json (rocprofv3 --pmc; not measured by this run)"}
+    except Exception:
+        valu = None
     roofline = None
     if dom:
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS,
@@ -486,7 +502,8 @@ def main():
                     "traffic_is": "HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/traffic.json "
                                   "(not measured by this run)" + ("; STALE: " + traffic_note if traffic_note else ""),
                     "bytes_per_launch": dom[1]["bytes"], "avg_launch_ms": round(dom[1]["avg_ms"], 5),
-                    "launches": dom[1]["calls"], "launches_are": "the launches of every %dth timed step" % PROFILE_EVERY}
+                    "launches": dom[1]["calls"], "launches_are": "the launches of every %dth timed step" % PROFILE_EVERY,
+                    "valu_issue": valu}
 
     # Whole-job value: every GPU advances one shard of `particles_per_gpu` particles per step, so the job
     # completes n_gpus shard-steps per step (== plain steps/s at n_gpus = 1).

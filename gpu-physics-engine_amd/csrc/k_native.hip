@@ -547,11 +547,49 @@ __device__ __forceinline__ bool pair_response(const bool active, float &p1x, flo
     const bool cand = active && q <= rs2 * 1.000001f && q >= 9.9e-9f;
     hit = false;
     if (__ballot(cand) == 0) return false;                            // wave-uniform
+#ifndef GPE_VAR_LEANMATH
+#define GPE_VAR_LEANMATH 1
+#endif
+#if GPE_VAR_LEANMATH
+    // The correctly rounded square root and quotients WITHOUT the steps hipcc's sequences spend on operands that
+    // cannot occur here: a candidate has q in [9.9e-9, 1.000001 rs^2] and the quotients' numerators are differences
+    // of positions (0 or >= one ulp of a position), so nothing is denormal, zero-divided, infinite or NaN; the lanes
+    // that are not candidates compute garbage that the selects below discard.
+    //   sqrt: v_sqrt_f32 is within 1 ulp; try the neighbours with an exact residual (one fma each).
+    //   x / d: r = 1/d refined once (shared by the two quotients); q0 = x r; q1 = q0 + (x - d q0) r; result =
+    //   q1 + (x - d q1) r -- the core of v_div_scale / v_div_fmas / v_div_fixup, which only add scaling and specials.
+    float distance;
+    {
+        const float s0 = __builtin_amdgcn_sqrtf(q);
+        const float s_dn = __int_as_float(__float_as_int(s0) - 1), s_up = __int_as_float(__float_as_int(s0) + 1);
+        const float r_dn = __builtin_fmaf(-s_dn, s0, q);
+        float sres = r_dn <= 0.0f ? s_dn : s0;
+        const float r_up = __builtin_fmaf(-s_up, s0, q);
+        sres = r_up > 0.0f ? s_up : sres;
+        distance = sres;                                              // :93
+    }
+    hit = cand && rs2 > distance * distance && distance > 0.0001f;    // :95
+    const float depth = radius_sum - distance;                        // :97
+    float ux, uy;
+    {
+        const float r0 = __builtin_amdgcn_rcpf(distance);
+        const float e0 = __builtin_fmaf(-distance, r0, 1.0f);
+        const float r1q = __builtin_fmaf(e0, r0, r0);
+        const float qx0 = vx * r1q, qy0 = vy * r1q;
+        const float qx1 = __builtin_fmaf(__builtin_fmaf(-distance, qx0, vx), r1q, qx0);
+        const float qy1 = __builtin_fmaf(__builtin_fmaf(-distance, qy0, vy), r1q, qy0);
+        ux = __builtin_fmaf(__builtin_fmaf(-distance, qx1, vx), r1q, qx1);
+        uy = __builtin_fmaf(__builtin_fmaf(-distance, qy1, vy), r1q, qy1);
+    }
+    const float cx = (ux * depth) * stiffness;                        // :98,101
+    const float cy = (uy * depth) * stiffness;
+#else
     const float distance = sqrtf(q);                                  // :93
     hit = cand && rs2 > distance * distance && distance > 0.0001f;    // :95
     const float depth = radius_sum - distance;                        // :97
     const float cx = ((vx / distance) * depth) * stiffness;           // :98,101
     const float cy = ((vy / distance) * depth) * stiffness;
+#endif
     float w1 = 0.5f, w2 = 0.5f;                                       // == inv1 / (inv1 + inv1), exactly
     const bool general = hit && !(r1 == r2 && r1_plain);
     if (__ballot(general) != 0) {                                     // wave-uniform: unequal radii somewhere
