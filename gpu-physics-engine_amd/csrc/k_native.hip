@@ -389,18 +389,22 @@ struct TileLds {
     // The exact cone is not a square (see kConeLeft ...): 5 / 4 cells left / right of the tile, 3 / 2 below / above.
     static constexpr int HXL = kConeLeft + 1, HXR = kConeRight + 1, HYL = kConeDown + 1, HYR = kConeUp + 1;
     static constexpr int RWX = T + HXL + HXR, RWY = T + HYL + HYR;
-    static constexpr int NCELL = RWX * RWY;
+    // The cell array carries a ring of one cell around the window: a kept particle's phantom cells then always have
+    // a slot (home + a constant offset, no bounds tests).  Ring cells lie outside every colour's zone: never walked.
+    static constexpr int PX = RWX + 2, PY = RWY + 2;
+    static constexpr int NCELL = PX * PY;
     static constexpr int NB = (T + 2 * kHalo) / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
     static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads;    // looked-up particles per thread
     static constexpr int RAWCAP = QMAX * kNatThreads;                     // looked-up particles a window takes
-    static_assert(RAWCAP < 8192 && NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | looked-up slot (13)");
+    static_assert(RAWCAP < 2048 && NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | own (1) | looked-up slot (11)");
     static constexpr int QZ = (T + 8) * (T + 4) / 4;                      // cells of one colour inside its zone
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
-    uint32_t hm[CAP];          // bits 0-10 local index of the home cell; bits 11-18 overlap mask of the 8 neighbour
-                               // cells (k_native_hash); bits 19-31 the particle's slot among the looked-up ones
+    uint32_t hm[CAP];          // bits 0-10 index of the home cell in the padded cell array; bits 11-18 overlap mask of
+                               // the 8 neighbour cells (k_native_hash); bit 19 the home cell lies in the tile (the
+                               // particle is the tile's own); bits 20-30 the particle's slot among the looked-up ones
     // cell[lc + 1]: members of cell lc (P1) -> first slot of its list (P2) -> one past its last slot (P3);
     // cell[0] = 0, so from P3 on the list of cell lc is mem[cell[lc] .. cell[lc + 1]).  Values stay below
     // 4 * CAP < 65536: two cells share a word (LDS atomics are 32 bit, so cell_inc adds 1 or 1 << 16 --
@@ -448,7 +452,8 @@ struct TileGlobal {
     // keeps every looked-up particle: slot == looked-up slot
     static constexpr int HXL = kHalo, HXR = kHalo, HYL = kHalo, HYR = kHalo;
     static constexpr int RWX = T + 2 * kHalo, RWY = T + 2 * kHalo;
-    static constexpr int NCELL = RWX * RWY;
+    static constexpr int PX = RWX + 2, PY = RWY + 2;               // padded as in TileLds
+    static constexpr int NCELL = PX * PY;
     static constexpr int NB = RWX / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;
@@ -861,6 +866,20 @@ __device__ __forceinline__ void resolve_wave_blocked(L &S, const uint32_t b, con
     }
 }
 
+// Offset of neighbour k (grid.wgsl:68-90 scan order: y outer, x inner, centre skipped) in a cell array of row
+// stride PX, eight signed bytes packed into one constant.
+template <int PX>
+__device__ __forceinline__ int neighbour_offset(const int k)
+{
+    static_assert(PX + 1 < 128, "offsets fit a signed byte");
+    constexpr unsigned long long packed =
+        ((unsigned long long)(uint8_t)(int8_t)(-PX - 1)) | ((unsigned long long)(uint8_t)(int8_t)(-PX) << 8) |
+        ((unsigned long long)(uint8_t)(int8_t)(-PX + 1) << 16) | ((unsigned long long)(uint8_t)(int8_t)(-1) << 24) |
+        ((unsigned long long)(uint8_t)(int8_t)(1) << 32) | ((unsigned long long)(uint8_t)(int8_t)(PX - 1) << 40) |
+        ((unsigned long long)(uint8_t)(int8_t)(PX) << 48) | ((unsigned long long)(uint8_t)(int8_t)(PX + 1) << 56);
+    return (int)(int8_t)(uint8_t)(packed >> (8 * k));
+}
+
 // One tile: returns false when the region exceeds the window's capacity (nothing written).
 // ORD: a sharded run -- the members of a cell are ordered by A.order_keys[local index] (the particle's index in the
 // unsharded system) instead of by the local index.  A template parameter, not a run-time test: the instantiation
@@ -870,7 +889,7 @@ template <bool ORD, class L>
 __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const int tx, const int ty)
 {
     constexpr int T = L::TILE;
-    constexpr int RWX = L::RWX, RWY = L::RWY, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
+    constexpr int RWX = L::RWX, RWY = L::RWY, PX = L::PX, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
     static_assert(NBLK <= 255, "sblk is 8 bit");
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -1029,21 +1048,19 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const uint32_t s = slot[q];
             const int lx = lxq[q], ly = lyq[q];
             S.px[s] = pp[q].x; S.py[s] = pp[q].y; S.rad[s] = pr[q]; S.id[s] = pid[q];
-            const int home = ly * RWX + lx;
+            const int home = (ly + 1) * PX + lx + 1;                  // index in the padded cell array
             S.cell_inc(home + 1);
             // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
             uint32_t over = (cc[q] >> 6) & 0xFFu;
             const uint32_t raw = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            S.hm[s] = (uint32_t)home | (over << 11) | (kTrim ? (raw << 19) : 0u);
+            const uint32_t own = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? (1u << 19) : 0u;
+            S.hm[s] = (uint32_t)home | (over << 11) | own | (kTrim ? (raw << 20) : 0u);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (over == 0) break;
                 const int k = __ffs((int)over) - 1;
                 over &= over - 1u;
-                const int nb = k + (k >> 2);                           // neighbour index (y+1)*3 + (x+1), 4 = centre
-                const int y3 = (nb * 11) >> 5;                         // nb / 3 for nb < 9
-                const int nlx = lx + (nb - 3 * y3) - 1, nly = ly + y3 - 1;
-                if (nlx >= 0 && nlx < RWX && nly >= 0 && nly < RWY) S.cell_inc(nly * RWX + nlx + 1);
+                S.cell_inc(home + neighbour_offset<PX>(k) + 1);       // (always inside the padded array)
             }
         }
     }
@@ -1082,20 +1099,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         uint32_t k = S.cell_inc(home + 1);
         S.mem[k] = s;
         uint32_t over = (hm >> 11) & 0xFFu;
-        const int lx = home % RWX, ly = home / RWX;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (over == 0) break;
             const int kb = __ffs((int)over) - 1;
             over &= over - 1u;
-            const int nb = kb + (kb >> 2);
-            const int y3 = (nb * 11) >> 5;
-            const int nlx = lx + (nb - 3 * y3) - 1, nly = ly + y3 - 1;
-            if (nlx >= 0 && nlx < RWX && nly >= 0 && nly < RWY) {
-                const int lc = nly * RWX + nlx;
-                k = S.cell_inc(lc + 1);
-                S.mem[k] = s;
-            }
+            k = S.cell_inc(home + neighbour_offset<PX>(kb) + 1);
+            S.mem[k] = s;
         }
     }
     __syncthreads();
@@ -1119,13 +1129,11 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
             const uint32_t sc = min(s, PS - 1u);                       // PS >= 1: the tile has particles of its own
             const uint32_t hm = S.hm[sc];
-            const int home = (int)(hm & 0x7FFu);
-            const int lx = home % RWX, ly = home / RWX;
-            const bool own = s < PS && lx >= HX && lx < HX + T && ly >= HY && ly < HY + T;
+            const bool own = s < PS && (hm & (1u << 19)) != 0;
             uint32_t id = S.id[sc];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if constexpr (ORD) {                                       // S.id holds the order key: find the block of
-                const uint32_t raw = hm >> 19;                         // the looked-up slot, re-read the local index
+                const uint32_t raw = hm >> 20;                         // the looked-up slot, re-read the local index
                 int lo = 0, hi = NBLK;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
@@ -1165,7 +1173,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 // colour - 1 = (gx & 1) + 2 * (gy & 1) (collision_solver.wgsl:55-58); ox + hx, oy + hy are even
-                lc[c] = (hy + (c >> 1)) * RWX + hx + (c & 1);
+                lc[c] = (hy + (c >> 1) + 1) * PX + hx + (c & 1) + 1;
                 cnt[c] = 0;
                 if (i < QC) cnt[c] = S.cell_get(lc[c] + 1) - S.cell_get(lc[c]);
             }
@@ -1318,9 +1326,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     } else
     for (uint32_t s = tid; s < PS; s += kNatThreads) {
         const uint32_t hm = S.hm[s];
-        const int home = (int)(hm & 0x7FFu);
-        const int lx = home % RWX, ly = home / RWX;
-        if (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) {
+        if (hm & (1u << 19)) {                                         // the tile's own particle
             uint32_t id = S.id[s];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if constexpr (ORD) {                                       // S.id holds the order key: find the block of
