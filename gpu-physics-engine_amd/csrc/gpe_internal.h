@@ -103,16 +103,29 @@ __device__ __forceinline__ uint32_t popc_below_lane(uint64_t m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// inclusive scan across the 64 lanes of a wave
+// inclusive scan across the 64 lanes of a wave: six DPP adds (row shifts by 1, 2, 4, 8 inside the 16-lane rows, then
+// the row totals broadcast from lane 15 into rows 1 and 3 and from lane 31 into rows 2 and 3) instead of six
+// ds_bpermute round trips through the LDS crossbar with a select each.  A source lane outside the row / wave reads
+// as 0 (bound_ctrl), which is the identity of the sum.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v = dpp_add<0x111, 0xF>(v);        // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);        // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);        // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);        // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
     return v;
+}
+// sum over the 64 lanes, the same in every lane
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
 }
 
 // exclusive scan of one value per thread over a 256-thread block; `total` receives the block sum.

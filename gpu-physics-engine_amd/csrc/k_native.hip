@@ -930,9 +930,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 const int bi = b % NB, bj = b / NB;
                 if (bi >= 1 && bi < NB - 1 && bj >= 1 && bj < NB - 1) own += cb;
             }
-            carry += __shfl(inc, 63, 64);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
-        for (int d = 32; d >= 1; d >>= 1) own += __shfl_xor(own, d, 64);
+        own = wave_sum(own);
         if (lane == 0) {
             S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[1] = own; S.misc[3] = 0;
             if (!L::kGlobal) S.misc[2] = 0;                            // main tile: "a cell of more than 64 members"
