@@ -641,6 +641,60 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
     }
 }
 
+// The one-lane cells of a wave -- 2 or 3 members, rarely a pile the wave list had no room for -- as straight-line
+// code on registers: slots in one LDS round trip, ids / positions / radii in a second, a three-element sorting
+// network (ascending object index, collision_solver.wgsl:66-118; a cell of two needs none: the response is symmetric
+// under exchanging the particles -- v -> -v negates the correction exactly, sums and products commute), the pairs
+// (0,1), (0,2), (1,2) back to back with pair_response's wave-uniform early-outs, the moved positions stored at the
+// end.  The general loop (resolve_cell) walked the same pairs through two nested loops with an LDS round trip per
+// partner: ~60 wave instructions and five dependent round trips more per pass.
+#ifndef GPE_VAR_SMALLCELLS
+#define GPE_VAR_SMALLCELLS 1
+#endif
+template <class L>
+__device__ __forceinline__ void resolve_small_cells(L &S, const bool on, const uint32_t b, const uint32_t n,
+                                                    const float stiffness)
+{
+    const bool small = on && n <= 3u;
+    const bool three = small && n == 3u;
+    uint32_t m0 = 0, m1 = 0, m2 = 0;
+    if (small) { m0 = S.mem[b]; m1 = S.mem[b + 1]; m2 = three ? (uint32_t)S.mem[b + 2] : m1; }
+    uint32_t i0 = 0, i1 = 1, i2 = 2;
+    float x0 = 0.f, y0 = 0.f, r0 = 1.f, x1 = 3.f, y1 = 3.f, r1 = 1.f, x2 = 6.f, y2 = 6.f, r2 = 1.f;
+    const bool any3 = __ballot(three) != 0;                            // wave-uniform
+    if (small) {
+        x0 = S.px[m0]; y0 = S.py[m0]; r0 = S.rad[m0];
+        x1 = S.px[m1]; y1 = S.py[m1]; r1 = S.rad[m1];
+    }
+    if (any3) {
+        if (three) { i0 = S.id[m0]; i1 = S.id[m1]; i2 = S.id[m2]; x2 = S.px[m2]; y2 = S.py[m2]; r2 = S.rad[m2]; }
+#define GPE_CSWAP(A, B)                                                                                       \
+        {                                                                                                     \
+            const bool sw = three && i##A > i##B;                                                             \
+            const uint32_t ta = sw ? i##B : i##A, tb = sw ? i##A : i##B, ma = sw ? m##B : m##A, mb = sw ? m##A : m##B; \
+            const float xa = sw ? x##B : x##A, xb = sw ? x##A : x##B, ya = sw ? y##B : y##A, yb = sw ? y##A : y##B;    \
+            const float ra = sw ? r##B : r##A, rb = sw ? r##A : r##B;                                         \
+            i##A = ta; i##B = tb; m##A = ma; m##B = mb; x##A = xa; x##B = xb; y##A = ya; y##B = yb; r##A = ra; r##B = rb; \
+        }
+        GPE_CSWAP(0, 1) GPE_CSWAP(1, 2) GPE_CSWAP(0, 1)
+#undef GPE_CSWAP
+    }
+    const bool plain0 = r0 >= 1e-30f && r0 <= 1e30f, plain1 = r1 >= 1e-30f && r1 <= 1e30f;
+    bool h01 = false, h02 = false, h12 = false;
+    (void)pair_response(small, x0, y0, x1, y1, r0, r1, plain0, stiffness, h01);
+    if (any3) {
+        (void)pair_response(three, x0, y0, x2, y2, r0, r2, plain0, stiffness, h02);
+        (void)pair_response(three, x1, y1, x2, y2, r1, r2, plain1, stiffness, h12);
+    }
+    if (h01 | h02) { S.px[m0] = x0; S.py[m0] = y0; }
+    if (h01 | h12) { S.px[m1] = x1; S.py[m1] = y1; }
+    if (h02 | h12) { S.px[m2] = x2; S.py[m2] = y2; }
+    if (on && n > 3u) {                                                // a pile in the one-lane list: the general walk
+        sort_members(S, b, b + n);
+        resolve_cell(S, b, b + n, stiffness);
+    }
+}
+
 // A cell of 4..8 members resolved by kGroupLanes consecutive lanes of one wave.  The reference's pair sequence
 // (a, b), a < b in ascending object index (:68-118) only orders pairs that share a particle; pair (a, b) can
 // run as soon as (a, b-1) and (a-1, b) are done, i.e. at step a + b - 1 of a wavefront schedule -- 2n - 3 steps
@@ -1263,15 +1317,22 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 if (!(GPE_DBG_SKIP & 8))
 #endif
                 resolve_group(S, b, e - b, (int)(i % kGroupLanes), A.stiffness);
-            } else if (i >= single_base && i < work) {
-                const int lc = S.list[k * L::QZ + (i - single_base)];
-                const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
+            } else if (i >= single_base && (i & ~63u) < work) {         // (whole waves: the walk uses ballots)
+                const bool on = i < work;
+                uint32_t b = 0, e = 0;
+                if (on) {
+                    const int lc = S.list[k * L::QZ + (i - single_base)];
+                    b = S.cell_get(lc); e = S.cell_get(lc + 1);
+                }
 #ifdef GPE_DBG_SKIP
                 if (!(GPE_DBG_SKIP & 16))
 #endif
                 {
-                    sort_members(S, b, e);
-                    resolve_cell(S, b, e, A.stiffness);
+#if GPE_VAR_SMALLCELLS
+                    resolve_small_cells(S, on, b, e - b, A.stiffness);
+#else
+                    if (on) { sort_members(S, b, e); resolve_cell(S, b, e, A.stiffness); }
+#endif
                 }
             }
         }
