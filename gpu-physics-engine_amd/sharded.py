@@ -396,16 +396,21 @@ class ShardedState:
                               "rccl" if (not self.stage_cpu and dist.get_backend(self.group) == "nccl") else "torch")
         if want == "rccl":
             try:
+                # every rank takes part in the broadcast whatever happened on rank 0: a failure there travels as an
+                # all-zero id, so that all ranks leave this transport together instead of waiting for each other
                 ident = torch.zeros(L.COMM_ID_BYTES, dtype=torch.uint8)
                 if dist.get_rank(self.group) == 0:
                     raw = (C.c_uint8 * L.COMM_ID_BYTES)()
-                    L.check(L.load().gpe_comm_unique_id(raw))
-                    ident = torch.tensor(list(raw), dtype=torch.uint8)
+                    if L.load().gpe_comm_unique_id(raw) == L.GPE_OK:
+                        ident = torch.tensor(list(raw), dtype=torch.uint8)
                 comm_dev = e.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
                 ident = ident.to(comm_dev)
                 src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
                 dist.broadcast(ident, src=src, group=self.group)
-                raw = (C.c_uint8 * L.COMM_ID_BYTES)(*ident.cpu().tolist())
+                ident = ident.cpu()
+                if not bool(ident.any()):
+                    raise RuntimeError("rank 0 could not create an RCCL id: %s" % (L.load().gpe_last_error(None) or b"").decode())
+                raw = (C.c_uint8 * L.COMM_ID_BYTES)(*ident.tolist())
                 torch.cuda.synchronize(e.device)
                 e.ctx.call("gpe_shard_comm_init", raw, self.rank, self.ws)          # collective
                 self.transport = "rccl"

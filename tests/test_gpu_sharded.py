@@ -218,3 +218,103 @@ def test_sharded_blob_crosses_the_handover_threshold(gpe, tmp_path):
     order = np.argsort(gid)
     assert np.array_equal(np.concatenate(poss)[order], want_pos)
     assert np.array_equal(np.concatenate(prevs)[order], want_prev)
+
+
+def test_rccl_communicator_in_the_library_single_rank(gpe):
+    """The in-library RCCL transport on real hardware as far as one GPU allows (RCCL refuses two ranks on one
+    device): librccl loads, ncclGetUniqueId / ncclCommInitRank (1 rank) / ncclCommDestroy work on the context's
+    device, and an exchange without a plan is refused loudly rather than attempted."""
+    import ctypes as C
+    n = 2000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=3)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    lib = gpe._lib.load()
+    assert lib.gpe_comm_probe() == 0
+    ident = (C.c_uint8 * gpe._lib.COMM_ID_BYTES)()
+    assert lib.gpe_comm_unique_id(ident) == 0, lib.gpe_last_error(None)
+    assert any(bytes(ident))
+    st.ctx.call("gpe_shard_comm_init", ident, 0, 1)
+    with pytest.raises(gpe.GpeError) as e:
+        st.ctx.call("gpe_shard_exchange")                  # no gpe_shard_configure yet
+    assert e.value.status == gpe._lib.GPE_ERR_STATE
+    st.ctx.call("gpe_shard_comm_destroy")
+    st.update(1 / 60, resort=True)                         # the context is unharmed
+    st.ctx.sync()
+    st.close()
+
+
+def test_rccl_exchange_moves_a_segment_on_hardware(gpe):
+    """gpe_shard_exchange's RCCL path on a real device: a one-rank communicator and a plan whose only "neighbour" is the
+    rank itself, so the grouped ncclSend / ncclRecv pair of that slot moves the packed segment from the send buffer
+    into the receive buffer through RCCL, on the context's stream -- the call sequence, sizes and offsets of the
+    multi-GPU run, minus the second GPU this box does not have."""
+    import ctypes as C
+    L = gpe._lib
+    n = 4000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=4)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    ctx = st.ctx
+    ctx.call("gpe_use_order_keys", 1)
+    cs = np.float32(0.5) * np.float32(2.2)
+    gx = int(np.floor(np.float32(world[0]) / cs)) + 1
+    gy = int(np.floor(np.float32(world[1]) / cs)) + 1
+    bx, by = (gx + 7) // 8, (gy + 7) // 8
+    ctx.call("gpe_set_active_cells", 0, 0, gx - 1, gy - 1)
+
+    def dev(nbytes, fill=None):
+        p = C.c_void_p()
+        ctx.call("gpe_buffer_alloc", nbytes, C.byref(p))
+        data = np.zeros(nbytes, np.uint8) if fill is None else fill
+        ctx.call("gpe_buffer_upload", p, data.ctypes.data_as(C.c_void_p), data.nbytes)
+        return p
+
+    cap_mig, cap_gho = 8, 16
+    words = 4 + 6 * cap_mig + 4 * cap_gho
+    own_words = 4 + 4 * 8
+    owner, mask = dev(bx * by), dev(bx * by * 4)           # rank 0 owns every block, nothing borders another rank
+    send, recv = dev((words + own_words + 16) * 4), dev((words + 16) * 4)
+    plan = L.GpeShardPlan()
+    plan.struct_size = C.sizeof(L.GpeShardPlan)
+    plan.rank, plan.world_size, plan.n_slots = 0, 1, 2
+    plan.blocks_x, plan.blocks_y = bx, by
+    plan.d_owner_of_block, plan.d_dest_mask_of_block = owner.value, mask.value
+    plan.slot_rank[0], plan.send_off[0], plan.send_cap_mig[0], plan.send_cap_gho[0] = 0, 0, cap_mig, cap_gho
+    plan.recv_off[0], plan.recv_cap_mig[0], plan.recv_cap_gho[0] = 0, cap_mig, cap_gho
+    plan.slot_rank[1], plan.send_off[1], plan.send_cap_mig[1], plan.send_cap_gho[1] = 0, words, 0, 8
+    plan.recv_off[1], plan.recv_cap_mig[1], plan.recv_cap_gho[1] = words, 0, 0
+    plan.d_send, plan.d_recv = send.value, recv.value
+    ctx.call("gpe_shard_configure", C.byref(plan))
+    ident = (C.c_uint8 * L.COMM_ID_BYTES)()
+    assert L.load().gpe_comm_unique_id(ident) == 0
+    ctx.call("gpe_shard_comm_init", ident, 0, 1)
+    keys_ptr, nbytes = C.c_void_p(), C.c_uint64()
+    ctx.call("gpe_device_ptr", L.ORDER_KEYS, C.byref(keys_ptr), C.byref(nbytes))
+    keys = np.arange(n, dtype=np.uint32)                   # order keys = local indices: the run must equal a plain one
+    ctx.call("gpe_buffer_upload", keys_ptr, keys.ctypes.data_as(C.c_void_p), keys.nbytes)
+    ctx.call("gpe_shard_begin")                            # packs (nothing borders anything: empty segments)
+    # the step loop of a sharded run inside the library: 6 x { RCCL exchange, unpack, step, pack }
+    ctx.call("gpe_shard_run", 1.0 / 60.0, 6)
+    no, nt = C.c_uint64(), C.c_uint64()
+    ctx.call("gpe_shard_counts", C.byref(no), C.byref(nt), 1)
+    assert (no.value, nt.value) == (n, n)
+    plain = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    plain.run(1 / 60, 6, resort_every=0, resort_first=False)
+    assert np.array_equal(st.positions(), plain.positions())
+    assert np.array_equal(st.previous_positions(), plain.previous_positions())
+    plain.close()
+    ctx.call("gpe_shard_begin")
+    ctx.sync()
+    pattern = (np.arange(words, dtype=np.uint32) * np.uint32(2654435761)) | np.uint32(1)
+    pattern[0:4] = 0                                       # header: no rows, so that a later unpack has nothing to do
+    ctx.call("gpe_buffer_upload", send, pattern.ctypes.data_as(C.c_void_p), pattern.nbytes)
+    ctx.call("gpe_shard_exchange")
+    ctx.sync()
+    got = np.zeros(words, np.uint32)
+    ctx.call("gpe_buffer_download", recv, got.ctypes.data_as(C.c_void_p), got.nbytes)
+    assert np.array_equal(got, pattern)
+    ctx.call("gpe_shard_comm_destroy")
+    for p in (owner, mask, send, recv):
+        ctx.call("gpe_buffer_free", p)
+    st.close()
