@@ -1033,12 +1033,16 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 
     // ---- P1: gather the region's particles (all loads of a thread in flight together), count the
     //          cell memberships -----------------------------------------------------------------------
-    for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QMAX * kNatThreads) {   // one round unless the window spills
-        uint32_t pid[QMAX], blk[QMAX], cc[QMAX];
-        float2 pp[QMAX];
-        float pr[QMAX];
+    // Two rounds of 512 looked-up particles per pass of this loop: the window takes three (QMAX), but the mean tile
+    // looks up 1.7 x 512, so the third round's instructions -- executed by every wave whether or not a lane has a
+    // particle -- are left to a second pass that a scalar branch skips unless P > 1024.
+    constexpr int QP = QMAX >= 2 ? 2 : 1;
+    for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QP * kNatThreads) {
+        uint32_t pid[QP], blk[QP], cc[QP];
+        float2 pp[QP];
+        float pr[QP];
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) {
+        for (int q = 0; q < QP; ++q) {
             // Branch-free on purpose: behind `if (s < P)` hipcc merges the loaded value with the default through
             // register copies that wait for the load (s_waitcnt vmcnt(0) right behind it), so the rounds' loads ran one
             // after the other -- three dependent global round trips.  Slots beyond P re-read slot P - 1 (a cache hit)
@@ -1048,11 +1052,11 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
         }
 #ifdef GPE_TILE_STAMPS
-        { uint32_t acc = 0; for (int q = 0; q < QMAX; ++q) acc += pid[q]; asm volatile("" :: "v"(acc)); }
+        { uint32_t acc = 0; for (int q = 0; q < QP; ++q) acc += pid[q]; asm volatile("" :: "v"(acc)); }
         GPE_STAMP(7);
 #endif
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) {
+        for (int q = 0; q < QP; ++q) {
             pp[q] = A.pos_in[pid[q]];
             pr[q] = A.radius[pid[q]];
             cc[q] = A.codes[pid[q]];
@@ -1061,19 +1065,19 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         // up again at write-back (P6)
         if constexpr (ORD) {
 #pragma unroll
-            for (int q = 0; q < QMAX; ++q) pid[q] = A.order_keys[pid[q]];
+            for (int q = 0; q < QP; ++q) pid[q] = A.order_keys[pid[q]];
         }
 #ifdef GPE_TILE_STAMPS
-        { float acc = 0; for (int q = 0; q < QMAX; ++q) acc += pp[q].x + pr[q]; asm volatile("" :: "v"(acc)); }
+        { float acc = 0; for (int q = 0; q < QP; ++q) acc += pp[q].x + pr[q]; asm volatile("" :: "v"(acc)); }
         GPE_STAMP(8);
 #endif
         // home cell: the slot's block among the looked-up ones + the cell inside the block (k_native_hash),
         // relative to the cell window; particles whose home lies outside the window are dropped here
-        int lxq[QMAX], lyq[QMAX];
-        bool keep[QMAX];
-        uint32_t slot[QMAX];
+        int lxq[QP], lyq[QP];
+        bool keep[QP];
+        uint32_t slot[QP];
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) {
+        for (int q = 0; q < QP; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             lxq[q] = (int)(blk[q] % NB) * 8 + (int)(cc[q] & 7u) - (kHalo - HX);
             lyq[q] = (int)(blk[q] / NB) * 8 + (int)((cc[q] >> 3) & 7u) - (kHalo - HY);
@@ -1082,22 +1086,22 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         }
         if constexpr (kTrim) {
             // kept particles get consecutive slots: one LDS atomic per wave (the order of the slots is free)
-            uint64_t mq[QMAX];
+            uint64_t mq[QP];
             uint32_t cnt = 0;
 #pragma unroll
-            for (int q = 0; q < QMAX; ++q) { mq[q] = __ballot(keep[q]); cnt += (uint32_t)__popcll(mq[q]); }
+            for (int q = 0; q < QP; ++q) { mq[q] = __ballot(keep[q]); cnt += (uint32_t)__popcll(mq[q]); }
             uint32_t base = 0;
             if (lane == 0 && cnt) base = atomicAdd(&S.misc[3], cnt);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
-            for (int q = 0; q < QMAX; ++q) {
+            for (int q = 0; q < QP; ++q) {
                 slot[q] = base + popc_below_lane(mq[q]);
                 base += (uint32_t)__popcll(mq[q]);
                 keep[q] = keep[q] && slot[q] < (uint32_t)(sizeof(S.px) / sizeof(float));   // over capacity: see below
             }
         }
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) {
+        for (int q = 0; q < QP; ++q) {
             if (!keep[q]) continue;
             const uint32_t s = slot[q];
             const int lx = lxq[q], ly = lyq[q];
@@ -1181,6 +1185,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
             const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            own_id[q] = 0xFFFFFFFFu;
+            fetch[q] = 0u;
+            if (q >= 2 && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar: the third round is nearly always empty)
             const uint32_t sc = min(s, PS - 1u);                       // PS >= 1: the tile has particles of its own
             const uint32_t hm = S.hm[sc];
             const bool own = s < PS && (hm & (1u << 19)) != 0;
@@ -1201,6 +1208,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
             own_prev[q] = make_float2(0.f, 0.f);
+            if (q >= 2 && PS <= (uint32_t)q * kNatThreads) continue;
             if (A.fuse_verlet) own_prev[q] = A.prev[fetch[q]];
         }
     }
