@@ -102,6 +102,11 @@ constexpr int kTileMain = 32, kCapMain = GPE_CAP_MAIN;
 // workgroups per CU (with 1920 / 2048-particle windows it ran two: half the waves to hide latency with).
 constexpr int kTileMid = 16, kCapMid = 1200;
 constexpr int kTileSmall = 8, kCapSmall = 1200;
+// sharded (order-key) instantiations: 4 more bytes per slot for the local index, so 1024 slots in the same LDS
+#ifndef GPE_CAP_ORD
+#define GPE_CAP_ORD 1024
+#endif
+constexpr int kCapOrd = GPE_CAP_ORD;
 // population of a 3x3-block (24x24-cell) window = what an 8x8 sub-tile looks up (it keeps ~56 % of it):
 constexpr uint32_t kWindowReport = 512;     // tiles report windows above this population
 // Windows beyond the 8x8 sub-tile's 1536 slots take their arrays from the spill arena; with the cells of up to
@@ -380,10 +385,14 @@ struct CollideArgs {
 #define GPE_STAMP(i) do {} while (0)
 #endif
 
-template <int T, int CAP>
+// LID: a sharded run's windows also keep every particle's local index (4 bytes per slot): `id` then holds the order key
+// the members are sorted by, and the write-back needs the local index again.
+template <int T, int CAP, bool LID = false>
 struct TileLds {
     static constexpr int TILE = T;
     static constexpr bool kGlobal = false;
+    static constexpr bool kLid = LID;
+    uint32_t lid[LID ? CAP : 1];
     // The blocks of tile +- 8 cells are looked up (block granule), but only particles whose home cell lies within
     // +- 5 cells are kept: 23 % fewer particles in LDS at 32x32, and the window overflows that much later.
     // The exact cone is not a square (see kConeLeft ...): 5 / 4 cells left / right of the tile, 3 / 2 below / above.
@@ -396,7 +405,8 @@ struct TileLds {
     static constexpr int NB = (T + 2 * kHalo) / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
-    static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads;    // looked-up particles per thread
+    // looked-up particles per thread: the window keeps ~2/3 of what it looks up, so three rounds whatever the capacity
+    static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads < 3 ? 3 : (CAP + kNatThreads - 1) / kNatThreads;
     static constexpr int RAWCAP = QMAX * kNatThreads;                     // looked-up particles a window takes
     static_assert(RAWCAP < 2048 && NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | own (1) | looked-up slot (11)");
     static constexpr int QZ = (T + 8) * (T + 4) / 4;                      // cells of one colour inside its zone
@@ -449,6 +459,7 @@ template <int T>
 struct TileGlobal {
     static constexpr int TILE = T;
     static constexpr bool kGlobal = true;
+    static constexpr bool kLid = false;
     // keeps every looked-up particle: slot == looked-up slot
     static constexpr int HXL = kHalo, HXR = kHalo, HYL = kHalo, HYR = kHalo;
     static constexpr int RWX = T + 2 * kHalo, RWY = T + 2 * kHalo;
@@ -1063,6 +1074,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         }
         // sharded run: the member order is the particle's index in the unsharded system; the local index is looked
         // up again at write-back (P6)
+        uint32_t lidq[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) lidq[q] = pid[q];
         if constexpr (ORD) {
 #pragma unroll
             for (int q = 0; q < QP; ++q) pid[q] = A.order_keys[pid[q]];
@@ -1106,6 +1120,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const uint32_t s = slot[q];
             const int lx = lxq[q], ly = lyq[q];
             S.px[s] = pp[q].x; S.py[s] = pp[q].y; S.rad[s] = pr[q]; S.id[s] = pid[q];
+            if constexpr (L::kLid) S.lid[s] = lidq[q];
             const int home = (ly + 1) * PX + lx + 1;                  // index in the padded cell array
             S.cell_inc(home + 1);
             // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
@@ -1174,7 +1189,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // (a scalar, so that comparing against it waits for no load: the count of a sharded run is read here, once)
     const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
-    constexpr int QOWN = QMAX;                                         // ceil(window capacity / threads)
+    constexpr int QOWN = ((int)(sizeof(S.px) / sizeof(float)) + kNatThreads - 1) / kNatThreads;   // ceil(kept capacity / threads)
     uint32_t own_id[QOWN];
     float2 own_prev[QOWN];
     if constexpr (kTrim) {
@@ -1193,7 +1208,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const bool own = s < PS && (hm & (1u << 19)) != 0;
             uint32_t id = S.id[sc];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
-            if constexpr (ORD) {                                       // S.id holds the order key: find the block of
+            if constexpr (ORD && L::kLid) {
+                id = S.lid[sc];                                        // S.id holds the order key; the local index was kept
+            } else if constexpr (ORD) {                                // S.id holds the order key: find the block of
                 const uint32_t raw = hm >> 20;                         // the looked-up slot, re-read the local index
                 int lo = 0, hi = NBLK;
                 while (hi - lo > 1) {
@@ -1430,7 +1447,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 template <int T, int CAP, bool ORD>
 __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide_dense(CollideArgs A)
 {
-    __shared__ TileLds<T, CAP> S;
+    __shared__ TileLds<T, CAP, ORD> S;
     const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
     const uint32_t per_xcd = (total + 7u) / 8u;
     const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -1453,8 +1470,8 @@ __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide
 template <bool ORD>
 __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs A)
 {
-    using Mid = TileLds<kTileMid, kCapMid>;
-    using Small = TileLds<kTileSmall, kCapSmall>;
+    using Mid = TileLds<kTileMid, ORD ? kCapOrd : kCapMid, ORD>;
+    using Small = TileLds<kTileSmall, ORD ? kCapOrd : kCapSmall, ORD>;
     using Spill = TileGlobal<kTileSmall>;
     __shared__ union U { Mid mid; Small small; Spill spill; } u;
     uint32_t count = A.tile_ctl[kCtlOverflow1];
@@ -1825,7 +1842,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
         const uint32_t grid = ((total + 7u) / 8u) * 8u;
         if (A.order_keys)
-            hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+            hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
         else
             hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
