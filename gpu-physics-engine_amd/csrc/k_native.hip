@@ -392,6 +392,7 @@ struct TileLds {
     static constexpr int TILE = T;
     static constexpr bool kGlobal = false;
     static constexpr bool kLid = LID;
+    static constexpr int kSlots = CAP;                 // particles the window keeps
     uint32_t lid[LID ? CAP : 1];
     // The blocks of tile +- 8 cells are looked up (block granule), but only particles whose home cell lies within
     // +- 5 cells are kept: 23 % fewer particles in LDS at 32x32, and the window overflows that much later.
@@ -460,6 +461,7 @@ struct TileGlobal {
     static constexpr int TILE = T;
     static constexpr bool kGlobal = true;
     static constexpr bool kLid = false;
+    static constexpr int kSlots = 1;                   // (no per-lane own arrays: the write-back loops over the slots)
     // keeps every looked-up particle: slot == looked-up slot
     static constexpr int HXL = kHalo, HXR = kHalo, HYL = kHalo, HYR = kHalo;
     static constexpr int RWX = T + 2 * kHalo, RWY = T + 2 * kHalo;
@@ -1189,7 +1191,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // (a scalar, so that comparing against it waits for no load: the count of a sharded run is read here, once)
     const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
-    constexpr int QOWN = ((int)(sizeof(S.px) / sizeof(float)) + kNatThreads - 1) / kNatThreads;   // ceil(kept capacity / threads)
+    constexpr int QOWN = (L::kSlots + kNatThreads - 1) / kNatThreads;  // ceil(kept capacity / threads)
     uint32_t own_id[QOWN];
     float2 own_prev[QOWN];
     if constexpr (kTrim) {
