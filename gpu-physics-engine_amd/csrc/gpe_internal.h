@@ -247,7 +247,8 @@ struct OnesweepWorkspace {
     uint32_t *bases4 = nullptr;      // 4 x 256 exclusive digit bases
     uint32_t *ctl = nullptr;         // [0..3] tile tickets per pass, [4] error word
     uint32_t epoch = 0;
-    bool hist_clean = false;         // hist4 (all copies) is zero: the native step keeps it so between steps
+    bool hist_clean = false;         // the set the next native step adds into is zero: the native step keeps it so
+    uint32_t hist_set = 0;           // which of the two sets of copies that is
 };
 
 // Native (N-key sort + LDS cell windows) pipeline state
@@ -432,7 +433,8 @@ gpe_status onesweep_zero_hist(gpe_ctx *c);
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
                          uint32_t **out_vals, bool bases_ready = false, uint2 *table = nullptr,
-                         uint32_t table_entries = 0);   // table: the last pass also fills the native block table
+                         uint32_t table_entries = 0,    // table: the last pass also fills the native block table
+                         const uint32_t *hist_src = nullptr);   // bases_ready: histogram copies the passes scan themselves
 // native pipeline (k_native.hip)
 gpe_status native_configure(gpe_ctx *c);
 bool native_should_run(gpe_ctx *c);

@@ -172,19 +172,18 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
                                                             int32_t blocks_y, uint32_t pad_key,
                                                             uint32_t *__restrict__ keys,
                                                             uint16_t *__restrict__ codes, int digits,
-                                                            uint32_t *hist4, uint32_t *__restrict__ bases4,
+                                                            uint32_t *hist4, uint32_t *__restrict__ hist_next,
                                                             uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl,
                                                             uint4 *__restrict__ table2, uint64_t table_pairs,
                                                             uint32_t *__restrict__ host_stat)
 {
     __shared__ uint32_t s_hist[4 * 256];
-    __shared__ uint32_t s_w[kHashBlock / 64];
-    __shared__ uint32_t s_last;
     s_hist[threadIdx.x] = 0;
     // What a step accumulates into is reset here instead of by a launch of its own (a launch costs ~6 us, 5 % of
     // the step at 1 M particles): the block table (filled two kernels later), and -- workgroup 0 -- the per-step
-    // control words, after handing the previous step's window statistic to the host (pinned memory).  The digit
-    // histograms are zeroed by the previous step's table kernel, the done-ticket by the workgroup that takes it last.
+    // control words, after handing the previous step's window statistic to the host (pinned memory), the radix
+    // passes' tile tickets, and the digit histograms the NEXT step's hash adds into (two sets, alternating steps:
+    // this step's set is read by the radix passes that follow, nobody touches the other one meanwhile).
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         table2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);      // (first, one past last) = (max, 0): empty
     if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords && threadIdx.x != kCtlHashDone) {
@@ -194,6 +193,10 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
             if (threadIdx.x == kCtlOverflow1) host_stat[kStatOverflow] = tile_ctl[kCtlOverflow1];
         }
         tile_ctl[threadIdx.x] = 0;
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kHashBlock) hist_next[i] = 0;
+        if (threadIdx.x < 8) os_ctl[threadIdx.x] = 0;                  // tile tickets + error word
     }
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -244,37 +247,16 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
     }
     if (oob) atomicOr(&tile_ctl[kCtlError], kErrOutOfBox);
     __syncthreads();
-    // Flush with RETURNING device-scope atomics and wait for the returns: when the barrier below opens, every
-    // add of this workgroup has been performed, so the ticket can follow without a release fence (an
-    // agent-scope fence here writes the L2 back -- the keys just stored -- once per workgroup: 3x the kernel).
+    // Flush: fire-and-forget device-scope atomics (the kernel boundary makes them visible); the radix passes turn the
+    // histograms into digit bases themselves (k_os_pass, hist_src), so no workgroup waits for the others here.
     if ((threadIdx.x & 1u) == 0) {
         // two neighbouring bins per 64-bit atomic (no bin reaches 2^32, so nothing carries into the upper one)
         const uint32_t lo = s_hist[threadIdx.x], hi = s_hist[threadIdx.x + 1];   // index = digit * 256 + bin
-        if (lo | hi) {
-            const unsigned long long old = __hip_atomic_fetch_add(
+        if (lo | hi)
+            __hip_atomic_fetch_add(
                 reinterpret_cast<unsigned long long *>(&hist4[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
                 (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" ::"v"((uint32_t)old));                     // the return value must have arrived
-        }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&tile_ctl[kCtlHashDone], 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (s_last == 0) return;
-    // k_os_prepare's job: exclusive digit bases per pass (four waves scan one digit), tile tickets reset
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < kHistCopies; ++k)
-        v += __hip_atomic_load(&hist4[k * 1024 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t inc = wave_inclusive_scan(v);
-    const int w = (int)(threadIdx.x >> 6);
-    if ((threadIdx.x & 63) == 63) s_w[w] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int i = w & ~3; i < w; ++i) base += s_w[i];
-    bases4[threadIdx.x] = base + inc - v;
-    if (threadIdx.x < 8) os_ctl[threadIdx.x] = 0;                      // tile tickets + error word
-    if (threadIdx.x == 0) tile_ctl[kCtlHashDone] = 0;                  // every workgroup has taken its ticket
 }
 
 // Largest particle count of any 3x3-block (24x24-cell) window: what the smallest cell window must hold.
@@ -1545,10 +1527,15 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
 {
     NativeState &N = c->native;
     const uint64_t n = c->n;
+    constexpr size_t kHistSet = (size_t)kHistCopies * 4 * 256;          // words of one set of digit histograms
     if (!c->os_ws.hist_clean) {                                        // another sort used the histograms since
-        GPE_HIP(c, hipMemsetAsync(c->os_ws.hist4, 0, (size_t)kHistCopies * 4 * 256 * sizeof(uint32_t), c->stream));
+        GPE_HIP(c, hipMemsetAsync(c->os_ws.hist4, 0, 2 * kHistSet * sizeof(uint32_t), c->stream));
         c->os_ws.hist_clean = true;
+        c->os_ws.hist_set = 0;
     }
+    uint32_t *hist_now = c->os_ws.hist4 + (size_t)c->os_ws.hist_set * kHistSet;
+    uint32_t *hist_next = c->os_ws.hist4 + (size_t)(c->os_ws.hist_set ^ 1u) * kHistSet;
+    c->os_ws.hist_set ^= 1u;
     {
         Scope s(c, "native/hash");
         const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;    // the table is allocated in 16-byte units
@@ -1557,17 +1544,17 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
         const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr;
         hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
                            c->cell_size, N.gx, N.gy, N.bx0, N.by0, N.blocks_x, N.blocks_y, N.table_entries, N.keys,
-                           N.codes, N.passes, c->os_ws.hist4, c->os_ws.bases4, c->os_ws.ctl, N.tile_ctl,
+                           N.codes, N.passes, hist_now, hist_next, c->os_ws.ctl, N.tile_ctl,
                            (uint4 *)N.block_table, pairs, N.host_stat);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
     {
         // the last radix pass also fills the block table (first / one-past-last position of every block, by
-        // atomic min / max at the ends of each tile's key runs) and zeroes the digit histograms for the next step
+        // atomic min / max at the ends of each tile's key runs); every pass derives its digit bases from hist_now
         Scope s(c, "native/sort");
         GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv, true,
-                              N.block_table, N.table_entries));
+                              N.block_table, N.table_entries, hist_now));
     }
     (void)sk;
     *sorted_ids = sv;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
                                                        uint32_t shift, uint32_t pass,
                                                        const uint32_t *__restrict__ bases4, u64 *status,
                                                        uint32_t *ctl, uint32_t epoch, uint2 *table,
-                                                       uint32_t table_entries, uint32_t *hist_zero)
+                                                       uint32_t table_entries, const uint32_t *__restrict__ hist_src)
 {
     constexpr int kOsItems = ITEMS, kOsTile = kOsBlock * ITEMS, kOsWaveSpan = 64 * ITEMS;   // shadow the defaults
     __shared__ uint32_t s_stage[kOsTile];
@@ -180,6 +180,18 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
         key[k] = valid ? keys_in[idx] : 0xffffffffu;
         if (IOTA) val[k] = (uint32_t)idx;
         else val[k] = valid ? vals_in[idx] : 0u;
+    }
+    // hist_src (the native step): the producer of the keys left the digit histograms (kHistCopies copies) and no
+    // bases -- every tile sums and scans its pass's 256 bins itself, the loads in flight beside the keys'.  That takes
+    // a serial "last workgroup scans" tail (~5 us) out of the producer.
+    uint32_t digit_base = 0;
+    if (hist_src) {
+        uint32_t v = 0;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int k = 0; k < kHistCopies; ++k) v += hist_src[k * 1024 + pass * 256 + threadIdx.x];
+        }
+        digit_base = os_block_exclusive_scan(v, s_w);              // threads >= 256 contribute 0, come last
     }
 #ifdef GPE_OS_STAMPS
     { uint32_t acc = 0; for (int k = 0; k < kOsItems; ++k) acc += key[k] + val[k]; asm volatile("" :: "v"(acc)); }
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
         if (failed) atomicOr(&ctl[4], 1u);
         __hip_atomic_store(mine, status_pack(epoch, kFlagPrefix, before + count), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        s_delta[d] = bases4[pass * 256 + d] + before - s_excl[d];
+        s_delta[d] = (hist_src ? digit_base : bases4[pass * 256 + d]) + before - s_excl[d];
     }
     __syncthreads();
     OS_STAMP(3);
@@ -350,9 +362,6 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
             }
         }
     }
-    // the digit histograms are dead once the passes have their bases: zero them for the next step's hash
-    if (hist_zero && tile == 0)
-        for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kOsBlock) hist_zero[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kOsItems; ++k) {
@@ -391,9 +400,10 @@ gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n)
     if (!ws.hist4) {
         // kHistCopies histograms (the fused hash kernel spreads its flush atomics over them; the generic
         // path uses copy 0), the digit bases, the control words
-        const size_t words = (size_t)kHistCopies * 4 * 256 + 4 * 256 + 64;
+        // (two sets of copies: the native step alternates between them)
+        const size_t words = 2 * (size_t)kHistCopies * 4 * 256 + 4 * 256 + 64;
         GPE_HIP(c, hipMalloc((void **)&ws.hist4, words * sizeof(uint32_t)));
-        ws.bases4 = ws.hist4 + (size_t)kHistCopies * 4 * 256;
+        ws.bases4 = ws.hist4 + 2 * (size_t)kHistCopies * 4 * 256;
         ws.ctl = ws.bases4 + 4 * 256;
         GPE_HIP(c, hipMemsetAsync(ws.hist4, 0, words * sizeof(uint32_t), c->stream));
     }
@@ -417,11 +427,13 @@ gpe_status onesweep_zero_hist(gpe_ctx *c)
 // Passes over digits [0, passes): (keys, vals) ping-pong with (keys_b, vals_b).  Returns through
 // *out_keys/*out_vals the buffers holding the result (the caller's when `passes` is even).
 // hist_ready: hist4 already holds the four digit histograms of `keys` (fused producer);
-// bases_ready: that producer has also done k_os_prepare's work (digit bases, tickets reset).
+// bases_ready: that producer has also reset the tickets, and the passes take their digit bases from hist_src
+// (kHistCopies histogram copies, summed and scanned by every tile).
 // iota_vals: the payload is the identity permutation and `vals` need not be initialised.
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
-                         uint32_t **out_vals, bool bases_ready, uint2 *table, uint32_t table_entries)
+                         uint32_t **out_vals, bool bases_ready, uint2 *table, uint32_t table_entries,
+                         const uint32_t *hist_src)
 {
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
@@ -458,7 +470,7 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
         const bool last = p == passes - 1;
         hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb, vb, n,
                            (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl, ws.epoch,
-                           last ? table : nullptr, table_entries, (last && table) ? ws.hist4 : nullptr);
+                           last ? table : nullptr, table_entries, (hist_ready && bases_ready) ? hist_src : nullptr);
         GPE_HIP(c, hipGetLastError());
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
