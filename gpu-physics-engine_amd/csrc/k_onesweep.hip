@@ -43,7 +43,7 @@ namespace gpe {
 #endif
 constexpr int kOsBlock = 512;
 constexpr int kOsWaves = kOsBlock / 64;
-// 8192-key tiles, look-back window of 8: measured best from 1 M to 100 M keys (2048-key tiles and a 32-word
+// 8192-key tiles: measured best from 1 M to 100 M keys (2048-key tiles and a 32-word look-back
 // window were each 10-50% slower per pass at 1 M, 4 M and 16 M keys -- profiles/r01/tune_onesweep.txt)
 constexpr int kOsItems = 16;                     // keys per thread: 8192-key tiles ...
 constexpr int kOsItemsSmall = 8;                 // ... and 4096-key tiles for small sorts: at 1 M keys 8192-key tiles
@@ -51,7 +51,9 @@ constexpr int kOsItemsSmall = 8;                 // ... and 4096-key tiles for s
                                                  // at 16 M and 100 M keys the small tiles are 20-33 % slower:
                                                  // profiles/r01/tune_onesweep_items.txt)
 constexpr uint64_t kOsSmallSort = 3u << 20;      // sorts up to this many keys take the small tiles
-constexpr int kWin = 8;
+constexpr int kWin = 4;                          // predecessors per look-back round trip: 4 beats 8 by 0.6 us per pass
+                                                 // at 1 M keys and by 15 us (3 %) at 100 M, 16 loses 1.6 us at 1 M
+                                                 // (profiles/r02/ab_lookback_window.txt)
 
 constexpr uint64_t kFlagAggregate = 1ull;        // value = this tile's count of the digit
 constexpr uint64_t kFlagPrefix = 2ull;           // value = count of the digit in tiles 0..this
