@@ -336,3 +336,73 @@ def test_gravity_soak_piles_up_without_error(gpe):
         assert np.array_equal(a.positions(), b.positions()), "after %d steps" % done
     assert np.isfinite(a.positions()).all()
     a.close(); b.close()
+
+
+def _fuzz_scene(seed):
+    """A random scene from a seed: world shape (down to less than one tile high), density, radii, gravity, time
+    step, re-sort pattern, and a share of particles put exactly on cell boundaries, on the walls and on top of
+    each other."""
+    rng = np.random.default_rng(0xF00D + seed)
+    n = int(rng.choice([1, 3, 70, 900, 5000, 12000, 30000]))
+    kind = rng.choice(["one", "mixed", "cont"])
+    if kind == "one":
+        rad = np.full(n, np.float32(rng.choice([0.5, 0.25, 2.0])), np.float32)
+    elif kind == "mixed":
+        rad = rng.choice(np.array([0.5, 1.0, 2.0, 3.0], np.float32), n).astype(np.float32)
+    else:
+        rad = (0.3 + 2.2 * rng.random(n, dtype=np.float32)).astype(np.float32)
+    max_r = float(np.abs(rad).max())
+    cell = float(np.float32(max_r) * np.float32(2.2))
+    density = float(rng.choice([0.03, 0.2, 0.6, 1.2]))                # particles per cell
+    aspect = float(rng.choice([1.0, 2.9, 17.0, 1 / 9.0, 60.0]))
+    cells = max(4.0, n / density)
+    h_cells = max(1.3, float(np.sqrt(cells / aspect)))
+    w_cells = max(1.3, cells / h_cells)
+    world = (float(np.float32(w_cells * cell + rng.random())), float(np.float32(h_cells * cell + rng.random())))
+    pos = (rng.random((n, 2), dtype=np.float32) * np.array(world, np.float32)).astype(np.float32)
+    k = n // 5
+    if k:
+        idx = rng.permutation(n)
+        a, b, c, d = idx[:k // 4], idx[k // 4:k // 2], idx[k // 2:3 * k // 4], idx[3 * k // 4:k]
+        pos[a, 0] = (np.floor(pos[a, 0] / np.float32(cell)) * np.float32(cell)).astype(np.float32)   # on a cell edge
+        pos[b, 1] = (np.floor(pos[b, 1] / np.float32(cell)) * np.float32(cell)).astype(np.float32)
+        pos[c, 0] = np.where(rng.random(len(c)) < 0.5, rad[c], np.float32(world[0]) - rad[c])        # on a wall
+        if len(d) > 1:
+            pos[d[1:]] = pos[d[0]] + (rng.random((len(d) - 1, 2), dtype=np.float32) * np.float32(1e-3)
+                                      * (rng.random() < 0.5)).astype(np.float32)                    # a clump
+    pos[:, 0] = np.clip(pos[:, 0], 0, np.float32(world[0]))
+    pos[:, 1] = np.clip(pos[:, 1], 0, np.float32(world[1]))
+    gravity = [(0.0, 0.0), (0.0, -9.81), (3.0, 7.5), (-20.0, 0.0)][int(rng.integers(4))]
+    dt = float(rng.choice([1 / 60, 1 / 30, 1 / 144]))
+    steps = int(rng.integers(5, 11))
+    resorts = set(int(x) for x in rng.choice(steps, size=int(rng.integers(1, 3)), replace=False)) | {0}
+    mouse = (world[0] * float(rng.random()), world[1] * float(rng.random())) if rng.random() < 0.25 else None
+    return pos, rad, world, max_r, gravity, dt, steps, resorts, mouse
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_native_fuzz_scenes_match_oracle(gpe, oracle, seed, monkeypatch):
+    """Seeded random scenes (ragged box sizes, thin worlds, boundary placements, clumps, several radii laws, gravity
+    in any direction, three time steps, re-sorts at random steps, mouse on in a quarter of them): bit-exact
+    positions, previous positions and particle ids after every step.  Even seeds pin the scene to the native
+    kernels (GPE_NATIVE_FORCE: clumps then go through the sub-tile and spill windows) and check that every step
+    ran there; odd seeds leave the choice to the step policy."""
+    pos, rad, world, max_r, gravity, dt, steps, resorts, mouse = _fuzz_scene(seed)
+    if seed % 2 == 0:
+        monkeypatch.setenv("GPE_NATIVE_FORCE", "1")
+    st = _native(gpe, pos, rad, world, gravity=gravity)
+    st.ctx.set_profiling(True)
+    p = oracle.default_params(world[0], world[1], max_r, gravity=gravity)
+    if mouse is not None:
+        p.mouse_pressed, p.mouse_x, p.mouse_y = 1, mouse[0], mouse[1]
+        st.particles.mouse_click_callback(True, mouse)
+    sim = oracle.Sim(pos, rad, p)
+    for s in range(steps):
+        st.update(dt, resort=(s in resorts)); sim.step(dt, resort=(s in resorts))
+        _assert_positions(st.positions(), sim.pos, "seed %d, step %d (n=%d, world %s)" % (seed, s, len(rad), world))
+    _assert_positions(st.previous_positions(), sim.prev, "seed %d previous positions" % seed)
+    assert np.array_equal(st.particles.download_particle_ids(), sim.particle_ids)
+    st.ctx.sync()
+    if seed % 2 == 0:
+        assert st.ctx.timings().get("native/collide+verlet", (0, 0))[1] == steps
+    st.close(); sim.close()
