@@ -145,8 +145,29 @@ static uint64_t num_chunks(const gpe_ctx *c)
     return (total_cell_ids(c) + GPE_COUNTING_CHUNK_SIZE - 1) / GPE_COUNTING_CHUNK_SIZE;
 }
 
+// The reference's grid / collision-cell buffers (4 entries per particle: 52 B per particle) and the sort
+// partners for 4N pairs (32 B per particle) are touched by the compat kernels only.  A COMPAT context allocates
+// them with the particles; a NATIVE context when something first asks for them: a per-module entry point
+// (gpe_grid_*, gpe_build_collision_cells, gpe_solve_collisions), array access, gpe_set_mode(COMPAT), or a step
+// the native kernels hand over (particles outside the box, over-dense windows) -- the one place where that costs
+// an allocation on the step path, once.  At 100 M particles that is 8.4 GB of 15 that stay unallocated.
+static gpe_status alloc_grid_buffers(gpe_ctx *c, uint64_t cap)
+{
+    gpe_status st = dev_alloc(c, &c->cell_ids, cap * 4);
+    if (st == GPE_OK) st = dev_alloc(c, &c->object_ids, cap * 4);
+    if (st == GPE_OK) st = dev_alloc(c, &c->chunk_obj_count, cap);
+    if (st == GPE_OK) st = dev_alloc(c, &c->collision_cells, cap * 4);
+    if (st == GPE_OK) st = dev_alloc(c, &c->indirect_args, 4);
+    if (st == GPE_OK) st = sort_reserve(c, cap * 4);
+    if (st != GPE_OK) {
+        dev_free(c->cell_ids); dev_free(c->object_ids); dev_free(c->chunk_obj_count);
+        dev_free(c->collision_cells); dev_free(c->indirect_args);
+    }
+    return st;
+}
+
 // Allocate every particle-count-dependent buffer for `cap` particles (State::new, state.rs:34-70).
-static gpe_status alloc_particle_buffers(gpe_ctx *c, uint64_t cap)
+static gpe_status alloc_particle_buffers(gpe_ctx *c, uint64_t cap, bool with_grid)
 {
     GPE_TRY(dev_alloc(c, &c->pos, cap));
     GPE_TRY(dev_alloc(c, &c->prev, cap));
@@ -156,14 +177,10 @@ static gpe_status alloc_particle_buffers(gpe_ctx *c, uint64_t cap)
     GPE_TRY(dev_alloc(c, &c->radius_copy, cap));
     GPE_TRY(dev_alloc(c, &c->home_cell_ids, cap));
     GPE_TRY(dev_alloc(c, &c->particle_ids, cap));
-    GPE_TRY(dev_alloc(c, &c->cell_ids, cap * 4));
-    GPE_TRY(dev_alloc(c, &c->object_ids, cap * 4));
-    GPE_TRY(dev_alloc(c, &c->chunk_obj_count, cap));
-    GPE_TRY(dev_alloc(c, &c->collision_cells, cap * 4));
-    GPE_TRY(dev_alloc(c, &c->indirect_args, 4));
     GPE_TRY(dev_alloc(c, &c->order_keys, cap));
     c->cap = cap;
-    GPE_TRY(sort_reserve(c, cap * 4));
+    if (with_grid) GPE_TRY(alloc_grid_buffers(c, cap));
+    else GPE_TRY(sort_reserve(c, cap));                                // the Morton re-sort's N pairs
     GPE_TRY(scan_reserve(c, cap));
     return GPE_OK;
 }
@@ -177,10 +194,25 @@ static gpe_status init_index_buffers(gpe_ctx *c, uint64_t lo, uint64_t hi)
     hipLaunchKernelGGL(k_iota_u32, dim3(stream_grid(cnt)), dim3(kStreamBlock), 0, c->stream,
                        c->particle_ids, lo, hi);                            // particle_sort.rs:30
     GPE_HIP(c, hipGetLastError());
+    if (!c->cell_ids) return GPE_OK;                                        // not allocated yet: need_grid_buffers
     GPE_TRY(fill_u32(c, c->cell_ids + 4 * lo, 4 * cnt, kUnused));           // grid.rs:80-83
     GPE_TRY(fill_u32(c, c->object_ids + 4 * lo, 4 * cnt, 0u));              // grid.rs:85-89
     GPE_TRY(fill_u32(c, c->collision_cells + 4 * lo, 4 * cnt, kUnused));    // collision_cell_buffers.rs:23-27
     GPE_TRY(fill_u32(c, c->chunk_obj_count + lo, cnt, 0u));                 // collision_cell_buffers.rs:17-21
+    return GPE_OK;
+}
+
+// Every user of the grid / collision-cell buffers calls this first (see alloc_grid_buffers).
+static gpe_status need_grid_buffers(gpe_ctx *c)
+{
+    if (c->cell_ids || c->cap == 0) return GPE_OK;
+    GPE_HIP(c, hipStreamSynchronize(c->stream));
+    GPE_TRY(alloc_grid_buffers(c, c->cap));
+    const uint64_t cnt = c->n;
+    GPE_TRY(fill_u32(c, c->cell_ids, 4 * cnt, kUnused));
+    GPE_TRY(fill_u32(c, c->object_ids, 4 * cnt, 0u));
+    GPE_TRY(fill_u32(c, c->collision_cells, 4 * cnt, kUnused));
+    GPE_TRY(fill_u32(c, c->chunk_obj_count, cnt, 0u));
     return GPE_OK;
 }
 
@@ -228,9 +260,11 @@ static gpe_status copy_into_new_buffers(gpe_ctx *c, const ParticleBufferSet &old
     GPE_HIP(c, hipMemcpyAsync(c->field, old.field, (count) * sizeof(*c->field), hipMemcpyDeviceToDevice, c->stream))
     GPE_COPY_OLD(pos, old_n); GPE_COPY_OLD(prev, old_n); GPE_COPY_OLD(radius, old_n);
     GPE_COPY_OLD(home_cell_ids, old_n); GPE_COPY_OLD(particle_ids, old_n);
-    GPE_COPY_OLD(cell_ids, 4 * old_n); GPE_COPY_OLD(object_ids, 4 * old_n);
-    GPE_COPY_OLD(chunk_obj_count, old_n); GPE_COPY_OLD(collision_cells, 4 * old_n);
-    GPE_COPY_OLD(indirect_args, 3);
+    if (old.cell_ids) {
+        GPE_COPY_OLD(cell_ids, 4 * old_n); GPE_COPY_OLD(object_ids, 4 * old_n);
+        GPE_COPY_OLD(chunk_obj_count, old_n); GPE_COPY_OLD(collision_cells, 4 * old_n);
+        GPE_COPY_OLD(indirect_args, 3);
+    }
     if (old.order_keys) GPE_COPY_OLD(order_keys, old_n);
 #undef GPE_COPY_OLD
     GPE_HIP(c, hipStreamSynchronize(c->stream));
@@ -242,7 +276,7 @@ static gpe_status grow_particle_buffers(gpe_ctx *c, uint64_t cap)
     const uint64_t old_n = c->n;
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     const ParticleBufferSet old = take_buffers(c);                     // the context now holds no particle buffer
-    gpe_status st = alloc_particle_buffers(c, cap);
+    gpe_status st = alloc_particle_buffers(c, cap, old.cell_ids != nullptr || c->cfg.mode != GPE_MODE_NATIVE);
     if (st == GPE_OK) st = copy_into_new_buffers(c, old, old_n);
     if (st != GPE_OK) {
         const std::string why = c->last_error;
@@ -303,6 +337,7 @@ static gpe_status do_resort(gpe_ctx *c)
 
 static gpe_status do_grid_sort(gpe_ctx *c)
 {
+    GPE_TRY(need_grid_buffers(c));
     Scope s(c, "Sort map");   // grid.rs:329
     return sort_pairs(c, c->cell_ids, c->object_ids, total_cell_ids(c));
 }
@@ -310,6 +345,7 @@ static gpe_status do_grid_sort(gpe_ctx *c)
 static gpe_status do_build_collision_cells(gpe_ctx *c)
 {
     // collision_cell_builder.rs:211-236
+    GPE_TRY(need_grid_buffers(c));
     GPE_TRY(launch_count_chunks(c, c->cell_ids, total_cell_ids(c), c->chunk_obj_count));
     {
         Scope s(c, "Collision cell prefix sum");   // collision_cell_builder.rs:227
@@ -322,6 +358,7 @@ static gpe_status do_build_collision_cells(gpe_ctx *c)
 
 static gpe_status do_solve_colors(gpe_ctx *c)
 {
+    GPE_TRY(need_grid_buffers(c));
     for (uint32_t color = 1; color <= 4; ++color)   // collision_solver.rs:224
         GPE_TRY(launch_solve_color(c, c->collision_cells, c->chunk_obj_count, num_chunks(c), c->cell_ids,
                                    c->object_ids, total_cell_ids(c), c->pos, c->radius, c->cfg.stiffness,
@@ -347,6 +384,7 @@ static gpe_status do_step_scoped(gpe_ctx *c, float dt, uint32_t flags)
         std::swap(c->pos, c->pos_copy);
         return GPE_OK;
     }
+    GPE_TRY(need_grid_buffers(c));
     GPE_TRY(launch_build_cell_ids(c, c->pos, c->radius, c->n, c->cell_size, c->cell_ids,
                                   c->object_ids));                               // :126 Grid::update
     GPE_TRY(do_grid_sort(c));
@@ -522,6 +560,7 @@ gpe_status gpe_set_mode(gpe_ctx *c, uint32_t mode)
     if (!c) return GPE_ERR_INVALID_ARG;
     if (mode != GPE_MODE_COMPAT && mode != GPE_MODE_NATIVE) return fail(c, GPE_ERR_INVALID_ARG, "unknown mode");
     c->cfg.mode = mode;
+    if (mode == GPE_MODE_COMPAT) GPE_TRY(need_grid_buffers(c));
     return reconfigure(c);
 }
 
@@ -536,7 +575,7 @@ gpe_status gpe_set_particles(gpe_ctx *c, const float *pos_xy, const float *prev_
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     if (n > c->cap) {
         free_particle_buffers(c);
-        gpe_status s = alloc_particle_buffers(c, n);
+        gpe_status s = alloc_particle_buffers(c, n, c->cfg.mode != GPE_MODE_NATIVE);
         if (s != GPE_OK) { free_particle_buffers(c); c->n = 0; return s; }
     }
     c->n = n;
@@ -652,6 +691,7 @@ gpe_status gpe_grid_build(gpe_ctx *c)
 {
     GPE_TRY(need_particles(c));
     GPE_HIP(c, hipSetDevice(c->device));
+    GPE_TRY(need_grid_buffers(c));
     return launch_build_cell_ids(c, c->pos, c->radius, c->n, c->cell_size, c->cell_ids, c->object_ids);
 }
 
@@ -715,9 +755,13 @@ gpe_status gpe_run(gpe_ctx *c, float dt, uint64_t steps, uint64_t resort_every, 
 }
 
 // ---- downloads ---------------------------------------------------------------------------------------------
-static gpe_status locate(gpe_ctx *c, gpe_array what, const void **ptr, uint64_t *bytes)
+static gpe_status locate(gpe_ctx *c, gpe_array what, const void **ptr, uint64_t *bytes, bool sizes_only = false)
 {
     const uint64_t n = c->n;
+    if (sizes_only) {}
+    else if (what == GPE_CELL_IDS || what == GPE_OBJECT_IDS || what == GPE_COLLISION_CELLS ||
+        what == GPE_NUM_COLLISION_CELLS || what == GPE_CHUNK_OBJ_COUNT || what == GPE_INDIRECT_ARGS)
+        GPE_TRY(need_grid_buffers(c));
     switch (what) {
         case GPE_POS: *ptr = c->pos; *bytes = n * 8; break;
         case GPE_PREV: *ptr = c->prev; *bytes = n * 8; break;
@@ -743,7 +787,7 @@ gpe_status gpe_array_bytes(const gpe_ctx *c, gpe_array what, uint64_t *bytes)
 {
     if (!c || !bytes) return GPE_ERR_INVALID_ARG;
     const void *p;
-    return locate(const_cast<gpe_ctx *>(c), what, &p, bytes);
+    return locate(const_cast<gpe_ctx *>(c), what, &p, bytes, true);
 }
 
 gpe_status gpe_device_ptr(gpe_ctx *c, gpe_array what, void **device_ptr, uint64_t *bytes)

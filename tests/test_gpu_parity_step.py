@@ -232,3 +232,35 @@ def test_max_radius_takes_the_last_of_equal_magnitudes(gpe):
         ctx.call("gpe_max_radius", C.byref(out))
         assert out.value == want, (radii, out.value)
         ctx.close()
+
+
+def test_native_context_allocates_grid_buffers_on_demand(gpe, oracle):
+    """A NATIVE context whose steps run on the native kernels does not hold the reference's 4N grid /
+    collision-cell arrays and 4N sort partners (84 B per particle); the first per-module call that needs them
+    allocates them, and the module calls then give the reference's results."""
+    import torch
+    n = 4_000_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=77)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    st.run(1 / 60, 3, resort_every=0, resort_first=True)
+    st.ctx.sync()
+    lean = free0 - torch.cuda.mem_get_info()[0]
+    st.grid.update()                                   # Grid::update -> the 4N arrays and the 4N sort partners
+    st.ctx.sync()
+    full = free0 - torch.cuda.mem_get_info()[0]
+    assert full - lean >= 72 * n, (lean, full)         # 52 B of 4N arrays + the sort partners growing from N to 4N
+    assert lean <= 200 * n + (96 << 20), (lean, full)  # SoA x 2, index arrays, native sort buffers, spill arena
+    # and the arrays hold what the oracle's grid holds for the same positions
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    for s in range(3):
+        sim.step(1 / 60, resort=(s == 0))
+    sim.grid_build(); sim.grid_sort()
+    cells = st.grid.download_cell_ids().ravel()
+    assert np.array_equal(cells, sim.cell_ids.ravel())
+    used = cells != 0xFFFFFFFF          # (the object ids of unused slots are whatever earlier steps left there:
+    assert used.sum() >= n              #  grid.wgsl writes them for used slots only, and these arrays are fresh)
+    assert np.array_equal(st.grid.download_object_ids().ravel()[used], sim.object_ids.ravel()[used])
+    st.close(); sim.close()
