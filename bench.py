@@ -301,14 +301,14 @@ def rehearse(args, rank, world_size):
 
 
 def kernel_source_digest():
-    """sha256 (16 hex digits) over the kernel sources: profiles/traffic.json records the digest its PMC numbers were
-    measured on, so a stale traffic figure is flagged instead of silently reported."""
+    """sha256 (16 hex digits) over the sources of the profiled kernels (hash, radix passes, collide: k_native.hip,
+    k_onesweep.hip and the shared header): profiles/traffic.json records the digest its PMC numbers were measured on,
+    so a stale traffic figure is flagged instead of silently reported."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gpu-physics-engine_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("gpe_internal.h", "k_native.hip", "k_onesweep.hip"):
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -23,9 +23,8 @@ def parse(path):
 def digest():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gpu-physics-engine_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("gpe_internal.h", "k_native.hip", "k_onesweep.hip"):     # as bench.py kernel_source_digest
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 native, sq = {}, {}
