@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--long-steps", type=int, default=2000,
+                    help="N = 1: the headline workload once more over this many timed steps (eight re-sorts inside the "
+                         "window; the cloud relaxes into touching clusters, so later steps resolve more pairs), "
+                         "reported under extra_workloads; 0 = skip")
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--mode", choices=["compat", "native"], default=os.environ.get("GPE_BENCH_MODE", "native"))
     ap.add_argument("--gravity", choices=["off", "on"], default="off")
@@ -446,6 +450,15 @@ def main():
             log("extra workload: %d particles, gravity on ..." % ne)
             extras.append(("%d particles, gravity on (0,-9.81) = BASELINE.json configs[2]" % ne,
                            run_workload(gpe, torch, None, 0, 1, ne, xs, 10, args.mode, "on", local_rank) + (None,), ne, sched))
+            if args.long_steps > 0:
+                log("extra workload: the headline workload over %d steps ..." % args.long_steps)
+                extras.append(("%d particles, gravity %s, %d timed steps: the headline workload over a long window "
+                               "(the cloud relaxes into touching clusters, later steps resolve more pairs)"
+                               % (n, args.gravity, args.long_steps),
+                               run_workload(gpe, torch, None, 0, 1, n, args.long_steps, args.warmup, args.mode,
+                                            args.gravity, local_rank) + (None,), n,
+                               "warm-up %d steps (first one re-sorts), %d timed steps, re-sort every %d steps of the run"
+                               % (args.warmup, args.long_steps, RESORT_EVERY), args.long_steps))
     soak = None
     if args.soak and world_size == 1:
         soak = run_soak(gpe, torch, args.extra_particles, args.mode, local_rank)
@@ -533,8 +546,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline(gpe, min(n, 1_000_000))
         result["cpu_baseline"]["value"] = round(result["cpu_baseline"]["value"], 4)
     if extras:
-        result["extra_workloads"] = [extra_entry(name, run, per, ngpu, args.extra_steps, mode, sched)
-                                     for name, run, per, sched in extras]
+        result["extra_workloads"] = [extra_entry(e[0], e[1], e[2], ngpu, e[4] if len(e) > 4 else args.extra_steps, mode, e[3])
+                                     for e in extras]
     if soak is not None:
         result["soak"] = soak
     print(json.dumps(result), flush=True)

@@ -22,7 +22,7 @@ for k, d in sorted(agg.items()):
     for c, v in sorted(d.items()): print("   %-28s per-dispatch %20.1f" % (c, v / max(1, cnt[k])))
 PY
 }
-for cfg in "1M --no-extra" "100M --particles 100000000 --gravity on --steps 20 --warmup 5 --no-extra"; do
+for cfg in "1M --steps 100 --warmup 10 --no-extra" "100M --particles 100000000 --gravity on --steps 20 --warmup 5 --no-extra"; do
   tag=${cfg%% *}; args=${cfg#* }
   echo "== kernel trace $tag =="
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$tag" -- python3 "$ROOT/bench.py" --no-cpu-baseline $args > "$OUT/trace_${tag}_bench.log" 2>&1
