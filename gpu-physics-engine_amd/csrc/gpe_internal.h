@@ -272,6 +272,8 @@ struct NativeState {
     void *arena = nullptr;           // global spill arena for those tiles' particle arrays (37 B per slot)
     uint64_t arena_cap = 0;          // slots
     bool force = false;              // GPE_NATIVE_FORCE=1 (tests): no hand-over to the compat kernels
+    bool print_stats = false;        // GPE_NATIVE_STATS=1: print the step statistics every 128 steps
+    uint32_t stat_calls = 0;
     uint32_t *host_stat = nullptr;   // pinned, 16 words (k_native.hip kStat*): window maximum, arena use, probe answer, overflow tiles
     uint32_t window_max = 0;         // the same, measured synchronously at configuration time
     bool dense_hold = false;         // left the native path because windows were filling up

@@ -83,7 +83,9 @@ constexpr uint32_t kErrBoundExceeded = 16u;    // sharded run: the device-side p
 constexpr int kCtlOverflow1 = 0;               // 32x32 tiles over capacity this step
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
 constexpr int kCtlArena = 3;                   // particles handed out of the global spill arena this step
-constexpr int kCtlHashDone = 4;                // hash workgroups that have flushed their histograms
+constexpr int kCtlOverflowTicket = 4;          // next work item of the over-capacity launch
+constexpr int kCtlSubTiles = 5;                // 16x16 quarters redone as four 8x8 tiles this step
+constexpr int kCtlSpills = 6;                  // 8x8 tiles staged in the global spill arena this step
 constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every step
 constexpr int kCtlError = 8;                   // sticky
 // pinned host words the kernels report to (read by the step policy with a lag of the steps in flight)
@@ -91,6 +93,7 @@ constexpr int kStatWindowMax = 0;              // largest 24x24-cell window popu
 constexpr int kStatArena = 1;                  // spill-arena slots handed out by the last native step
 constexpr int kStatProbe = 2;                  // window population measured by the last asynchronous probe + 1 (0: none yet)
 constexpr int kStatOverflow = 3;               // 32x32 tiles over capacity in the last native step
+constexpr int kStatSubTiles = 4, kStatSpills = 5;   // quarters redone as 8x8 tiles / 8x8 tiles through the arena (diagnostics)
 constexpr uint64_t kArenaBytesPerSlot = 37;
 constexpr uint64_t kArenaMaxSlots = 1ull << 30; // the arena's slot numbers are 32 bit; 40 GB of the 288 GB    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 // tile sizes (cells) and LDS capacities (particles staged per region)
@@ -186,11 +189,13 @@ __global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__rest
     // this step's set is read by the radix passes that follow, nobody touches the other one meanwhile).
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         table2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);      // (first, one past last) = (max, 0): empty
-    if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords && threadIdx.x != kCtlHashDone) {
+    if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords) {
         if (host_stat) {                                               // last step's statistics (kStat*), lagged
             if (threadIdx.x == kCtlWindowMax) host_stat[kStatWindowMax] = tile_ctl[kCtlWindowMax];
             if (threadIdx.x == kCtlArena) host_stat[kStatArena] = tile_ctl[kCtlArena];
             if (threadIdx.x == kCtlOverflow1) host_stat[kStatOverflow] = tile_ctl[kCtlOverflow1];
+            if (threadIdx.x == kCtlSubTiles) host_stat[kStatSubTiles] = tile_ctl[kCtlSubTiles];
+            if (threadIdx.x == kCtlSpills) host_stat[kStatSpills] = tile_ctl[kCtlSpills];
         }
         tile_ctl[threadIdx.x] = 0;
     }
@@ -1458,20 +1463,32 @@ __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs
     using Small = TileLds<kTileSmall, ORD ? kCapOrd : kCapSmall, ORD>;
     using Spill = TileGlobal<kTileSmall>;
     __shared__ union U { Mid mid; Small small; Spill spill; } u;
+    __shared__ uint32_t s_item;
     uint32_t count = A.tile_ctl[kCtlOverflow1];
     if (count > A.overflow1_cap) count = A.overflow1_cap;
     const uint32_t work = count * 4u;
-    for (uint32_t i = blockIdx.x; i < work; i += gridDim.x) {
+    if (work == 0) return;
+    // Work items are taken from a ticket counter: their durations differ by orders of magnitude (in a pile the
+    // quarters at the floor hold thousands of particles, the ones above them a few hundred), and a fixed stride
+    // of 1024 gives a workgroup the same quarter of every tile it meets.
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&A.tile_ctl[kCtlOverflowTicket], 1u);
+        __syncthreads();
+        const uint32_t i = s_item;
+        __syncthreads();
+        if (i >= work) break;
         const uint32_t parent = A.overflow1[i >> 2];
         const int tx = (int)((parent & 0xFFFFu) * 2u + (i & 1u)), ty = (int)((parent >> 16) * 2u + ((i >> 1) & 1u));
         const bool done = process_tile<ORD>(u.mid, A, tx, ty);
         __syncthreads();                                               // the union's views alias each other
         if (done) continue;
+        if (threadIdx.x == 0) atomicAdd(&A.tile_ctl[kCtlSubTiles], 1u);
         for (int sub = 0; sub < 4; ++sub) {
             const int sx = tx * 2 + (sub & 1), sy = ty * 2 + (sub >> 1);
             bool ok = process_tile<ORD>(u.small, A, sx, sy);
             __syncthreads();
             if (ok) continue;
+            if (threadIdx.x == 0) atomicAdd(&A.tile_ctl[kCtlSpills], 1u);
             ok = process_tile<ORD>(u.spill, A, sx, sy);
             __syncthreads();
             if (ok) continue;
@@ -1669,6 +1686,8 @@ gpe_status native_configure(gpe_ctx *c)
     // test hook: keep over-dense scenes on the native kernels (their windows then go through the spill arena)
     const char *force = getenv("GPE_NATIVE_FORCE");
     N.force = force && force[0] == '1';
+    const char *stats = getenv("GPE_NATIVE_STATS");                    // diagnostics: print the step statistics every 128 steps
+    N.print_stats = stats && stats[0] == '1';
     if (N.force) N.eligible = true;
     return GPE_OK;
 }
@@ -1722,6 +1741,11 @@ bool native_should_run(gpe_ctx *c)
     NativeState &N = c->native;
     if (c->cfg.mode != GPE_MODE_NATIVE) return false;
     const bool must_stay = N.force || c->use_order_keys;
+    if (N.print_stats && N.host_stat && (++N.stat_calls & 127u) == 0)
+        fprintf(stderr, "[gpe native] call %u: window max %u, arena slots used %u of %llu, 32x32 tiles over capacity %u, "
+                        "quarters redone as 8x8 tiles %u, 8x8 tiles through the arena %u\n", N.stat_calls,
+                N.host_stat[kStatWindowMax], N.host_stat[kStatArena], (unsigned long long)N.arena_cap,
+                N.host_stat[kStatOverflow], N.host_stat[kStatSubTiles], N.host_stat[kStatSpills]);
     if (!N.eligible && must_stay && N.in_box) { N.eligible = true; N.dense_hold = false; }   // density alone never stops such a run
     if (N.eligible) {
         if (N.host_stat && (uint64_t)N.host_stat[kStatArena] * 2 > N.arena_cap && N.arena_cap < kArenaMaxSlots) {
