@@ -393,10 +393,17 @@ struct TileLds {
     static constexpr int NB = (T + 2 * kHalo) / 8;
     static constexpr int NBLK = NB * NB;
     static constexpr int PER = (NCELL + kNatThreads - 1) / kNatThreads;   // cells per thread in the scan
-    // looked-up particles per thread: the window keeps ~2/3 of what it looks up, so three rounds whatever the capacity
-    static constexpr int QMAX = (CAP + kNatThreads - 1) / kNatThreads < 3 ? 3 : (CAP + kNatThreads - 1) / kNatThreads;
-    static constexpr int RAWCAP = QMAX * kNatThreads;                     // looked-up particles a window takes
-    static_assert(RAWCAP < 2048 && NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | own (1) | looked-up slot (11)");
+    // Looked-up particles a window takes (P0 hands the tile on when its 3x3 / 4x4 / 6x6 blocks hold more, before any
+    // gather): what the kept window holds at uniform density -- it keeps 66 % of what a 32x32 tile looks up, 51 % at
+    // 16x16, 38 % at 8x8 -- plus a margin; a tile that passes this test and still keeps more than CAP is handed on
+    // after the gather.  (Until the order-key windows kept their local indices this was bound to 1536 by an 11-bit
+    // slot field: an 8x8 tile went to the spill arena at 590 kept particles.)
+#ifndef GPE_QMAX_MAIN
+#define GPE_QMAX_MAIN 3
+#endif
+    static constexpr int QMAX = T >= 32 ? GPE_QMAX_MAIN : (T >= 16 ? 6 : 8);
+    static constexpr int RAWCAP = QMAX * kNatThreads;
+    static_assert(NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | own (1)");
     static constexpr int QZ = (T + 8) * (T + 4) / 4;                      // cells of one colour inside its zone
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
@@ -1114,9 +1121,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             S.cell_inc(home + 1);
             // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
             uint32_t over = (cc[q] >> 6) & 0xFFu;
-            const uint32_t raw = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             const uint32_t own = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? (1u << 19) : 0u;
-            S.hm[s] = (uint32_t)home | (over << 11) | own | (kTrim ? (raw << 20) : 0u);
+            S.hm[s] = (uint32_t)home | (over << 11) | own;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (over == 0) break;
@@ -1197,17 +1203,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const bool own = s < PS && (hm & (1u << 19)) != 0;
             uint32_t id = S.id[sc];
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
-            if constexpr (ORD && L::kLid) {
-                id = S.lid[sc];                                        // S.id holds the order key; the local index was kept
-            } else if constexpr (ORD) {                                // S.id holds the order key: find the block of
-                const uint32_t raw = hm >> 20;                         // the looked-up slot, re-read the local index
-                int lo = 0, hi = NBLK;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (S.boff[mid] <= raw) lo = mid; else hi = mid;
-                }
-                id = A.sorted_ids[S.bstart[lo] + (raw - S.boff[lo])];
-            }
+            static_assert(!ORD || L::kLid, "order-key windows keep the local indices");
+            if constexpr (ORD) id = S.lid[sc];                         // S.id holds the order key; the local index was kept
             own_id[q] = own ? id : 0xFFFFFFFFu;
             fetch[q] = (own && id < n_owned) ? id : 0u;
         }
