@@ -397,7 +397,10 @@ struct TileLds {
     // gather): what the kept window holds at uniform density -- it keeps 66 % of what a 32x32 tile looks up, 51 % at
     // 16x16, 38 % at 8x8 -- plus a margin; a tile that passes this test and still keeps more than CAP is handed on
     // after the gather.  (Until the order-key windows kept their local indices this was bound to 1536 by an 11-bit
-    // slot field: an 8x8 tile went to the spill arena at 590 kept particles.)
+    // slot field: an 8x8 tile went to the spill arena at 590 kept particles.)  The 32x32 tile stays at 1536: in a
+    // compressed scene its dense tiles are resolved faster as four quarters -- one crowded cell then holds up one
+    // quarter's colour pass, not 512 threads' (100 M soak at step 1500: 22.9 ms with 1536, 22.2 with 1280, 24.3 /
+    // 25.2 with 1700 / 1800 or 2048; profiles/r02/soak_1500_main_lookup_capacity.txt).
 #ifndef GPE_QMAX_MAIN
 #define GPE_QMAX_MAIN 3
 #endif
