@@ -1456,6 +1456,9 @@ __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide
 // indirect dispatch): one work item per 16x16 quarter.  A quarter whose 32x32-cell region is still over capacity
 // is redone by the same workgroup as four 8x8 tiles, and an 8x8 tile whose 24x24-cell window exceeds even that
 // LDS capacity gets its particle arrays from the global spill arena.  One launch, no queue, nothing to wait for.
+// (Eight waves per SIMD = 64 VGPRs: the kernel spills -- the item loop keeps the arguments of three inlined tile
+// walks live -- and is still faster than with 85 or 128 VGPRs and three or two workgroups per CU: 12.1 against 13.1 /
+// 15.2 ms in the compressed 100 M scene, profiles/r02/soak_1500_overflow_kernel_register_budget.txt.)
 template <bool ORD>
 __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs A)
 {
