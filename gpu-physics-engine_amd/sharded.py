@@ -315,6 +315,7 @@ class ShardedState:
         self.ws = dec.world_size
         self.n_owned = engine.n_owned
         self.n_ghost = 0
+        self._agree_on_cell_size()
         self.tables = engine.make_tables(dec, max(1 << 16, engine.capacity() // 4))
         engine.set_active_cells(dec.active_cells(rank))
         self.stats = {"migrants": 0, "ghosts": 0, "steps": 0}
@@ -332,6 +333,29 @@ class ShardedState:
         if self.fast:
             self._plan_device_exchange()
             self._setup_transport()
+
+    def _agree_on_cell_size(self):
+        """The cell size is 2.2 x the largest radius of the WHOLE system (grid.rs:159-161); a rank's context only
+        saw its own particles.  Every rank takes the maximum over the ranks (Grid::new's max_obj_radius) and checks
+        that the decomposition was cut with that cell size -- a rank on a different grid would exchange nonsense."""
+        e = self.e
+        if not isinstance(e, GpeEngine):
+            return
+        r = C.c_float(0.0)
+        e.ctx.call("gpe_max_radius", C.byref(r))
+        m = torch.tensor([abs(float(r.value))], dtype=torch.float64)
+        if self.ws > 1:
+            if dist.get_backend(self.group) == "nccl":
+                m = m.to(e.device)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        gmax = float(np.float32(m.item()))
+        if gmax != abs(float(r.value)):
+            e.ctx.call("gpe_grid_set_max_radius", gmax)
+        cs = C.c_float(0.0)
+        e.ctx.call("gpe_cell_size", C.byref(cs))
+        if np.float32(cs.value) != np.float32(self.dec.cell_size):
+            raise ValueError("sharded run: the decomposition was cut with cell size %r, the system's is %r "
+                             "(2.2 x the largest radius over all ranks)" % (float(self.dec.cell_size), float(cs.value)))
 
     # -- device-resident exchange --------------------------------------------------------------------------
     def _plan_device_exchange(self):

@@ -318,3 +318,67 @@ def test_rccl_exchange_moves_a_segment_on_hardware(gpe):
     for p in (owner, mask, send, recv):
         ctx.call("gpe_buffer_free", p)
     st.close()
+
+
+def _mixed_scene(n, world, seed):
+    """Radii 0.5 .. 3, the big ones (radius > 1) only in the right-hand third of the world: the ranks on the left hold
+    no particle of the largest radius, so their contexts derive a smaller cell size on their own."""
+    rng = np.random.default_rng(seed)
+    pos = (rng.random((n, 2), dtype=np.float32) * np.array(world, np.float32)).astype(np.float32)
+    rad = rng.choice(np.array([0.5, 0.75, 1.0], np.float32), n).astype(np.float32)
+    right = pos[:, 0] > np.float32(world[0] * 0.67)
+    rad[right] = rng.choice(np.array([0.5, 1.0, 2.0, 3.0], np.float32), int(right.sum())).astype(np.float32)
+    return pos, rad
+
+
+def _mixed_worker(rank, ws, port, n, world, gravity, steps, resort_at, dt, seed, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        pos, rad = _mixed_scene(n, world, seed)
+        cs = np.float32(np.abs(rad).max()) * np.float32(2.2)
+        dec = sharded.Decomposition(world, cs, ws, grid=(ws, 1))          # vertical strips: rank 0 is all small radii
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        if rank == 0:
+            assert np.abs(rad[mine]).max() < np.abs(rad).max()
+        eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, gravity=gravity, device=0)
+        st = sharded.ShardedState(eng, dec, rank, device_exchange=True)
+        assert st.fast
+        for s in range(steps):
+            st.update(dt, resort=(s in resort_at))
+        gid, p, q = st.owned()
+        eng.ctx.sync()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=gid, pos=p, prev=q)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mixed_radii_ranks_agree_on_the_cell_size(gpe, tmp_path):
+    """The cell size is 2.2 x the largest radius of the whole system; a rank that holds none of the big particles
+    must still use it (ShardedState._agree_on_cell_size).  Three ranks sharing the GPU, vertical strips, gravity
+    pushing particles across the cuts: bit-identical to the single-context run."""
+    ws, n, world, gravity = 3, 30_000, (1500.0, 500.0), (-60.0, -5.0)
+    steps, dt, seed, resort_at = 12, 0.05, 21, (0, 7)
+    port = _free_port()
+    mp.spawn(_mixed_worker, args=(ws, port, n, world, gravity, steps, resort_at, dt, seed, str(tmp_path)),
+             nprocs=ws, join=True)
+    pos, rad = _mixed_scene(n, world, seed)
+    ref = gpe.State(pos, rad, world=world, gravity=gravity, mode=gpe.MODE_NATIVE)
+    for s in range(steps):
+        ref.update(dt, resort=(s in resort_at))
+    want_pos, want_prev = ref.positions(), ref.previous_positions()
+    ref.close()
+    gids, poss, prevs = [], [], []
+    for r in range(ws):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        gids.append(d["gid"]); poss.append(d["pos"]); prevs.append(d["prev"])
+    gid = np.concatenate(gids)
+    assert np.array_equal(np.sort(gid), np.arange(n))
+    order = np.argsort(gid)
+    assert np.array_equal(np.concatenate(poss)[order], want_pos)
+    assert np.array_equal(np.concatenate(prevs)[order], want_prev)
