@@ -176,7 +176,9 @@ def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gr
     timings = eng.ctx.timings()
     _, p, _ = st.owned()
     info = {"owned": st.n_owned, "process_grid": [px, py],
-            "exchange": "device-resident (k_shard.hip pack/unpack, one all_to_all_single per step, no host sync)"
+            "exchange": ("device-resident (k_shard.hip pack/unpack, no host sync); segments moved by "
+                         + ("grouped ncclSend/ncclRecv inside the library (gpe_shard_run)" if st.transport == "rccl"
+                            else "a torch.distributed callback (all_to_all_single, staged through the host under gloo)"))
                         if st.fast else "torch (two host syncs per step)"}
     if st.fast:
         info["ghosts"] = st.n_ghost
