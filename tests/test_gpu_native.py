@@ -406,3 +406,31 @@ def test_native_fuzz_scenes_match_oracle(gpe, oracle, seed, monkeypatch):
     if seed % 2 == 0:
         assert st.ctx.timings().get("native/collide+verlet", (0, 0))[1] == steps
     st.close(); sim.close()
+
+
+@pytest.mark.parametrize("world,n", [((30000.0, 30000.0), 200_000),      # 27 k x 27 k cells, 11.6 M blocks: 3 radix passes
+                                     ((70000.0, 900.0), 150_000),        # 63 636 cell columns: just inside the 16-bit box
+                                     ((72000.0, 900.0), 50_000)])        # 65 455 columns: outside it -> compat kernels
+def test_native_sparse_huge_worlds(gpe, oracle, world, n):
+    """Worlds whose cell box approaches the 16-bit cell coordinates of the reference's Morton ids (grid.wgsl:101-108):
+    sparse clouds plus a dense patch so that pairs do collide; bit-exact against the oracle either side of the
+    eligibility limit (native_configure: more than 65000 columns or rows -> the compat kernels)."""
+    rng = np.random.default_rng(int(world[0]))
+    pos = (rng.random((n, 2), dtype=np.float32) * np.array(world, np.float32)).astype(np.float32)
+    k = n // 4                                                            # a patch at the far corner, ~1 per cell
+    side = float(np.sqrt(k) * 1.1)
+    pos[:k] = (np.array(world, np.float32) - np.float32(side) * rng.random((k, 2), dtype=np.float32)).astype(np.float32)
+    pos[:, 1] = np.clip(pos[:, 1], 0, np.float32(world[1]))
+    rad = np.full(n, 0.5, np.float32)
+    st = _native(gpe, pos, rad, world, gravity=(0.0, -9.81))
+    st.ctx.set_profiling(True)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5, gravity=(0.0, -9.81)))
+    for s in range(5):
+        st.update(1 / 60, resort=(s in (0, 3))); sim.step(1 / 60, resort=(s in (0, 3)))
+    _assert_positions(st.positions(), sim.pos, "huge sparse world %s" % (world,))
+    _assert_positions(st.previous_positions(), sim.prev, "previous positions")
+    assert np.array_equal(st.particles.download_particle_ids(), sim.particle_ids)
+    st.ctx.sync()
+    ran_native = st.ctx.timings().get("native/collide+verlet", (0, 0))[1]
+    assert ran_native == (5 if world[0] < 71000 else 0)
+    st.close(); sim.close()
