@@ -1431,6 +1431,48 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 }
 
 
+// One 16x16 quarter (tx, ty in 16-cell units) of an over-capacity 32x32 tile: as a 16x16 tile, else as four 8x8
+// tiles, and an 8x8 tile whose 24x24-cell window exceeds even that LDS capacity gets its particle arrays from the
+// global spill arena.
+template <bool ORD>
+struct OverflowLds {
+    using Mid = TileLds<kTileMid, ORD ? kCapOrd : kCapMid, ORD>;
+    using Small = TileLds<kTileSmall, ORD ? kCapOrd : kCapSmall, ORD>;
+    using Spill = TileGlobal<kTileSmall>;
+    union { Mid mid; Small small; Spill spill; };
+};
+template <bool ORD>
+__device__ __forceinline__ void resolve_quarter(OverflowLds<ORD> &u, const CollideArgs &A, const int tx, const int ty)
+{
+    using Spill = typename OverflowLds<ORD>::Spill;
+    const bool done = process_tile<ORD>(u.mid, A, tx, ty);
+    __syncthreads();                                                   // the union's views alias each other
+    if (done) return;
+    if (threadIdx.x == 0) atomicAdd(&A.tile_ctl[kCtlSubTiles], 1u);
+    for (int sub = 0; sub < 4; ++sub) {
+        const int sx = tx * 2 + (sub & 1), sy = ty * 2 + (sub >> 1);
+        bool ok = process_tile<ORD>(u.small, A, sx, sy);
+        __syncthreads();
+        if (ok) continue;
+        if (threadIdx.x == 0) atomicAdd(&A.tile_ctl[kCtlSpills], 1u);
+        ok = process_tile<ORD>(u.spill, A, sx, sy);
+        __syncthreads();
+        if (ok) continue;
+        // the spill arena is exhausted: flag it (gpe_sync / gpe_download report the error) and pass the
+        // tile's own particles through unresolved so that the state stays finite
+        if (threadIdx.x == 0) atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
+        for (int b = threadIdx.x; b < Spill::NBLK; b += kNatThreads) {
+            const int bi = b % Spill::NB, bj = b / Spill::NB;
+            if (bi < 1 || bi >= Spill::NB - 1 || bj < 1 || bj >= Spill::NB - 1) continue;
+            for (uint32_t q = 0; q < u.spill.bcnt[b]; ++q) {
+                const uint32_t id = A.sorted_ids[u.spill.bstart[b] + q];
+                A.pos_out[id] = A.pos_in[id];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Level 0: one workgroup per 32x32 tile, tiles dealt so that each XCD (blockIdx % 8) works through a
 // contiguous run of tile rows (neighbouring tiles share halo particles in that XCD's L2).
 template <int T, int CAP, bool ORD>
@@ -1442,7 +1484,9 @@ __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide
     const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
     const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
-    // a tile whose window exceeds the capacity returns early and is listed for k_collide_overflow
+    // A tile whose window exceeds the capacity returns early and is listed for k_collide_overflow.  (Redoing it
+    // here, quarter by quarter, on steps whose statistics let the host skip that launch: the extra code costs this
+    // kernel 3 % at 1 M and 5 % at 100 M, more than the 4.5 us launch: profiles/r02/ab_inline_fallback_rejected.txt.)
     if (!process_tile<ORD>(S, A, tx, ty)) {
         if (threadIdx.x == 0) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
@@ -1452,28 +1496,23 @@ __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide
     }
 }
 
-// Over-capacity 32x32 tiles are redone by a fixed grid that strides over the device-side list (HIP has no
-// indirect dispatch): one work item per 16x16 quarter.  A quarter whose 32x32-cell region is still over capacity
-// is redone by the same workgroup as four 8x8 tiles, and an 8x8 tile whose 24x24-cell window exceeds even that
-// LDS capacity gets its particle arrays from the global spill arena.  One launch, no queue, nothing to wait for.
+// Over-capacity 32x32 tiles are redone by a fixed grid that takes work items off the device-side list (HIP has no
+// indirect dispatch): one work item per 16x16 quarter.  One launch, nothing to wait for.
 // (Eight waves per SIMD = 64 VGPRs: the kernel spills -- the item loop keeps the arguments of three inlined tile
 // walks live -- and is still faster than with 85 or 128 VGPRs and three or two workgroups per CU: 12.1 against 13.1 /
 // 15.2 ms in the compressed 100 M scene, profiles/r02/soak_1500_overflow_kernel_register_budget.txt.)
 template <bool ORD>
 __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs A)
 {
-    using Mid = TileLds<kTileMid, ORD ? kCapOrd : kCapMid, ORD>;
-    using Small = TileLds<kTileSmall, ORD ? kCapOrd : kCapSmall, ORD>;
-    using Spill = TileGlobal<kTileSmall>;
-    __shared__ union U { Mid mid; Small small; Spill spill; } u;
+    __shared__ OverflowLds<ORD> u;
     __shared__ uint32_t s_item;
     uint32_t count = A.tile_ctl[kCtlOverflow1];
     if (count > A.overflow1_cap) count = A.overflow1_cap;
     const uint32_t work = count * 4u;
     if (work == 0) return;
-    // Work items are taken from a ticket counter: their durations differ by orders of magnitude (in a pile the
-    // quarters at the floor hold thousands of particles, the ones above them a few hundred), and a fixed stride
-    // of 1024 gives a workgroup the same quarter of every tile it meets.
+    // Work items are taken from a ticket counter: their durations differ by orders of magnitude (in a compressed scene
+    // the lower quarters of a tile hold several times the particles of the upper ones), and a fixed stride of 1024
+    // gives a workgroup the same quarter of every tile it meets.
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(&A.tile_ctl[kCtlOverflowTicket], 1u);
         __syncthreads();
@@ -1481,33 +1520,7 @@ __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs
         __syncthreads();
         if (i >= work) break;
         const uint32_t parent = A.overflow1[i >> 2];
-        const int tx = (int)((parent & 0xFFFFu) * 2u + (i & 1u)), ty = (int)((parent >> 16) * 2u + ((i >> 1) & 1u));
-        const bool done = process_tile<ORD>(u.mid, A, tx, ty);
-        __syncthreads();                                               // the union's views alias each other
-        if (done) continue;
-        if (threadIdx.x == 0) atomicAdd(&A.tile_ctl[kCtlSubTiles], 1u);
-        for (int sub = 0; sub < 4; ++sub) {
-            const int sx = tx * 2 + (sub & 1), sy = ty * 2 + (sub >> 1);
-            bool ok = process_tile<ORD>(u.small, A, sx, sy);
-            __syncthreads();
-            if (ok) continue;
-            if (threadIdx.x == 0) atomicAdd(&A.tile_ctl[kCtlSpills], 1u);
-            ok = process_tile<ORD>(u.spill, A, sx, sy);
-            __syncthreads();
-            if (ok) continue;
-            // the spill arena is exhausted: flag it (gpe_sync / gpe_download report the error) and pass the
-            // tile's own particles through unresolved so that the state stays finite
-            if (threadIdx.x == 0) atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
-            for (int b = threadIdx.x; b < Spill::NBLK; b += kNatThreads) {
-                const int bi = b % Spill::NB, bj = b / Spill::NB;
-                if (bi < 1 || bi >= Spill::NB - 1 || bj < 1 || bj >= Spill::NB - 1) continue;
-                for (uint32_t q = 0; q < u.spill.bcnt[b]; ++q) {
-                    const uint32_t id = A.sorted_ids[u.spill.bstart[b] + q];
-                    A.pos_out[id] = A.pos_in[id];
-                }
-            }
-            __syncthreads();
-        }
+        resolve_quarter<ORD>(u, A, (int)((parent & 0xFFFFu) * 2u + (i & 1u)), (int)((parent >> 16) * 2u + ((i >> 1) & 1u)));
     }
 }
 
