@@ -163,11 +163,14 @@ __device__ __forceinline__ uint32_t neighbour_overlap_mask(float2 p, float r, in
 }
 
 // Every workgroup flushes up to 256 bins per digit with device-scope atomics (they resolve beyond the per-XCD
-// L2s): FEW, LARGE workgroups (1024 lanes, at most one per CU) keep the flush small however many particles
-// there are.
+// L2s), so the workgroups are large (1024 lanes).  The kernel is bound by instruction issue and latency, not by
+// HBM: two workgroups per CU (64 VGPRs: two positions per lane in flight instead of eight) and up to 2048 of them
+// take it from 544 to 454 us at 100 M particles and from 98 to 84 us at 16 M, the extra flushes included
+// (profiles/r02/ab_hash_occupancy.txt).
 constexpr int kHashBlock = 1024;
-constexpr int kHashBatch = 8;                  // positions loaded per lane before any of them is ranked
-__global__ __launch_bounds__(kHashBlock) void k_native_hash(const float2 *__restrict__ pos,
+constexpr int kHashBatch = 2;                  // positions loaded per lane before any of them is ranked
+constexpr int kHashGridMax = 2048;
+__global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__restrict__ pos,
                                                             const float *__restrict__ radius, uint64_t n,
                                                             const uint32_t *__restrict__ n_valid_ptr,
                                                             float cell_size, int32_t gx, int32_t gy,
@@ -1572,8 +1575,8 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     {
         Scope s(c, "native/hash");
         const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;    // the table is allocated in 16-byte units
-        // one workgroup per CU at most, at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
-        const int grid = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
+        // at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
+        const int grid = (int)std::min<uint64_t>(kHashGridMax, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
         const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr;
         hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
                            c->cell_size, N.gx, N.gy, N.bx0, N.by0, N.blocks_x, N.blocks_y, N.table_entries, N.keys,
