@@ -264,3 +264,30 @@ def test_native_context_allocates_grid_buffers_on_demand(gpe, oracle):
     assert used.sum() >= n              #  grid.wgsl writes them for used slots only, and these arrays are fresh)
     assert np.array_equal(st.grid.download_object_ids().ravel()[used], sim.object_ids.ravel()[used])
     st.close(); sim.close()
+
+
+def test_switching_pipelines_mid_run_keeps_the_trajectory(gpe, oracle):
+    """gpe_set_mode (ABI only: the reference has one pipeline): NATIVE -> COMPAT -> NATIVE in the middle of a run.
+    The first switch is what allocates the reference's 4N arrays in a context created NATIVE; positions stay
+    bit-identical to the oracle throughout."""
+    n = 50_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.mixed_radius_cloud(n, gpe.scenes.world_for(n, density=0.05), seed=91)
+    world = gpe.scenes.world_for(n, density=0.05)
+    g = (0.0, -9.81)
+    st = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_NATIVE)
+    st.ctx.set_profiling(True)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], float(np.abs(rad).max()), gravity=g))
+    for phase, mode in enumerate([None, gpe.MODE_COMPAT, gpe.MODE_NATIVE]):
+        if mode is not None:
+            st.ctx.call("gpe_set_mode", mode)
+        for s in range(4):
+            resort = (phase == 0 and s == 0) or (phase == 2 and s == 1)
+            st.update(1 / 60, resort=resort); sim.step(1 / 60, resort=resort)
+        assert np.array_equal(st.positions().view(np.uint32), sim.pos.view(np.uint32)), "phase %d" % phase
+        assert np.array_equal(st.previous_positions().view(np.uint32), sim.prev.view(np.uint32)), "phase %d" % phase
+    st.ctx.sync()
+    tim = st.ctx.timings()
+    assert tim["native/collide+verlet"][1] == 8                    # phases 0 and 2 ran on the native kernels
+    assert tim["Sort map"][1] == 4                                 # phase 1 on the reference's pipeline (grid.rs:329)
+    st.close(); sim.close()
