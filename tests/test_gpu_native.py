@@ -434,3 +434,32 @@ def test_native_sparse_huge_worlds(gpe, oracle, world, n):
     ran_native = st.ctx.timings().get("native/collide+verlet", (0, 0))[1]
     assert ran_native == (5 if world[0] < 71000 else 0)
     st.close(); sim.close()
+
+
+def test_native_growth_then_module_calls(gpe, oracle):
+    """A NATIVE context grows (add_particles beyond its capacity) while the reference's 4N arrays do not exist yet,
+    steps on the native kernels, and only then is asked for Grid::update and the collision-cell list: those arrays
+    are allocated at the grown capacity and hold what the oracle's hold (used slots)."""
+    n = 3000
+    world = (260.0, 150.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=61)
+    extra_pos, extra_rad = gpe.scenes.uniform_cloud(5000, world, seed=62)          # > capacity: the buffers grow
+    st = _native(gpe, pos, rad, world)
+    st.update(1 / 60, resort=True)
+    cur, prev, perm = st.positions(), st.previous_positions(), st.particles.download_particle_ids()
+    st.add_particles(extra_pos, extra_rad)
+    sim = oracle.Sim(np.concatenate([cur, extra_pos]), np.concatenate([rad[perm], extra_rad]),
+                     oracle.default_params(world[0], world[1], 0.5), prev=np.concatenate([prev, extra_pos]))
+    for s in range(3):
+        st.update(1 / 60, resort=(s == 1)); sim.step(1 / 60, resort=(s == 1))
+    _assert_positions(st.positions(), sim.pos, "positions after growth (native)")
+    st.grid.update(); st.collision_system.build_collision_cells()
+    sim.grid_build(); sim.grid_sort(); sim.build_collision_cells()
+    cells = st.grid.download_cell_ids().ravel()
+    assert np.array_equal(cells, sim.cell_ids.ravel())
+    used = cells != 0xFFFFFFFF
+    assert np.array_equal(st.grid.download_object_ids().ravel()[used], sim.object_ids.ravel()[used])
+    k = sim.num_collision_cells
+    assert st.collision_system.num_collision_cells() == k
+    assert np.array_equal(st.collision_system.download_collision_cells().ravel()[:k], sim.collision_cells.ravel()[:k])
+    st.close(); sim.close()
