@@ -463,3 +463,23 @@ def test_native_growth_then_module_calls(gpe, oracle):
     assert st.collision_system.num_collision_cells() == k
     assert np.array_equal(st.collision_system.download_collision_cells().ravel()[:k], sim.collision_cells.ravel()[:k])
     st.close(); sim.close()
+
+
+def test_relaxed_cloud_long_run_native_equals_compat(gpe):
+    """Gravity off, the headline scene run long (6000 steps at 1 M): the cloud relaxes into touching clusters, the
+    densest tiles approach (and, later in such runs, exceed) the LDS capacity.  Same bits as the compat kernels at
+    every checkpoint, no error."""
+    n = 1_000_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    a = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    b = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
+    done = 0
+    for chunk in (2000, 2000, 2000):
+        a.run(1 / 60, chunk, resort_every=240, resort_first=(done == 0))
+        b.run(1 / 60, chunk, resort_every=240, resort_first=(done == 0))
+        done += chunk
+        a.ctx.sync()
+        assert np.array_equal(a.positions(), b.positions()), "after %d steps" % done
+        assert np.array_equal(a.previous_positions(), b.previous_positions()), "after %d steps" % done
+    a.close(); b.close()
