@@ -16,6 +16,13 @@ GPE_ERR_NO_DEVICE = -6
 
 MODE_COMPAT = 0
 MODE_NATIVE = 1
+FLAG_NATIVE_FORCE = 1
+FLAG_SORT_EVERY_STEP = 2
+FLAG_NATIVE_STATS = 4
+FLAG_SAFE_SORT = 8
+PIPELINE_COMPAT, PIPELINE_NATIVE = 0, 1
+(REASON_NONE, REASON_MODE_COMPAT, REASON_NO_PARTICLES, REASON_OUT_OF_BOX, REASON_GRID_TOO_WIDE,
+ REASON_TABLE_TOO_LARGE, REASON_DENSE_WINDOWS) = range(7)
 STEP_RESORT = 1
 
 UNUSED_CELL_ID = 0xFFFFFFFF
@@ -34,8 +41,14 @@ class GpeConfig(C.Structure):
         ("gravity_x", C.c_float), ("gravity_y", C.c_float),
         ("cell_size_multiplier", C.c_float), ("stiffness", C.c_float),
         ("mouse_strength", C.c_float), ("mode", C.c_uint32), ("profiling", C.c_uint32),
-        ("reserved", C.c_uint32 * 5),
+        ("flags", C.c_uint32), ("reserved", C.c_uint32 * 4),
     ]
+
+
+class GpePipelineInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("pipeline", C.c_uint32), ("reason", C.c_uint32),
+                ("sort_passes", C.c_uint32), ("native_steps", C.c_uint64), ("compat_steps", C.c_uint64),
+                ("native_sorts", C.c_uint64), ("window_max", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GpeTiming(C.Structure):
@@ -98,6 +111,7 @@ SYMBOLS = [
     ("gpe_run", _I32, [_VP, _F, _U64, _U64, _I32]),
     ("gpe_sync", _I32, [_VP]),
     ("gpe_set_mode", _I32, [_VP, _U32]),
+    ("gpe_get_pipeline_info", _I32, [_VP, C.POINTER(GpePipelineInfo)]),
     ("gpe_download", _I32, [_VP, C.c_int, _VP, _U64]),
     ("gpe_array_bytes", _I32, [_VP, C.c_int, C.POINTER(_U64)]),
     ("gpe_device_ptr", _I32, [_VP, C.c_int, C.POINTER(_VP), C.POINTER(_U64)]),

@@ -375,6 +375,7 @@ static gpe_status do_step_scoped(gpe_ctx *c, float dt, uint32_t flags)
         return fail(c, GPE_ERR_UNSUPPORTED,
                     "order keys (sharded run) need the native pipeline: mode NATIVE, particles inside the world "
                     "box, bounded density");
+    (native ? c->native.native_steps : c->native.compat_steps) += 1;
     if (native) {
         // grid update + collision solve as N-key sort + LDS cell windows (k_native.hip); the resolved
         // positions land in the scratch set, which then becomes the live one.  The integration (:130) is
@@ -431,8 +432,9 @@ gpe_status gpe_config_default(gpe_config *cfg)
     cfg->cell_size_multiplier = 2.2f;    // grid.rs:20
     cfg->stiffness = 0.6f;               // collision_solver.wgsl:2
     cfg->mouse_strength = 150.0f;        // particle_integration.wgsl:22
-    cfg->mode = GPE_MODE_COMPAT;
+    cfg->mode = GPE_MODE_NATIVE;         // (falls back to the COMPAT kernels by itself: gpe_get_pipeline_info)
     cfg->profiling = 0;
+    cfg->flags = 0;
     return GPE_OK;
 }
 
@@ -475,7 +477,7 @@ gpe_status gpe_create(const gpe_config *cfg, gpe_ctx **out)
     c->device = dev;
     c->profiling = local.profiling != 0;
     c->profile_every = local.profiling;
-    if (const char *e = getenv("GPE_SORT")) c->use_onesweep = strcmp(e, "safe") != 0;
+    c->use_onesweep = (local.flags & GPE_FLAG_SAFE_SORT) == 0;
     if ((e = hipSetDevice(dev)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         std::string m = std::string("gpe_create: ") + hipGetErrorName(e);
@@ -553,6 +555,33 @@ gpe_status gpe_sync(gpe_ctx *c)
     if (!c) return GPE_ERR_INVALID_ARG;
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     return check_device_errors(c);
+}
+
+gpe_status gpe_get_pipeline_info(gpe_ctx *c, gpe_pipeline_info *info)
+{
+    if (!c || !info) return GPE_ERR_INVALID_ARG;
+    if (info->struct_size == 0 || info->struct_size > sizeof(gpe_pipeline_info))
+        return fail(c, GPE_ERR_INVALID_ARG, "gpe_get_pipeline_info: bad struct_size");
+    gpe_pipeline_info out;
+    memset(&out, 0, sizeof(out));
+    out.struct_size = info->struct_size;
+    const NativeState &N = c->native;
+    if (c->cfg.mode != GPE_MODE_NATIVE) { out.pipeline = GPE_PIPELINE_COMPAT; out.reason = GPE_REASON_MODE_COMPAT; }
+    else if (c->n == 0) { out.pipeline = GPE_PIPELINE_COMPAT; out.reason = GPE_REASON_NO_PARTICLES; }
+    else if (N.eligible || ((N.force || c->use_order_keys) && N.in_box)) { out.pipeline = GPE_PIPELINE_NATIVE; out.reason = GPE_REASON_NONE; }
+    else { out.pipeline = GPE_PIPELINE_COMPAT; out.reason = N.reason; }
+    out.sort_passes = (uint32_t)N.passes;
+    out.native_steps = N.native_steps;
+    out.compat_steps = N.compat_steps;
+    out.window_max = N.host_stat ? N.host_stat[0] : 0u;
+    if (N.tile_ctl) {
+        uint32_t sorts = 0;
+        GPE_HIP(c, hipMemcpyAsync(&sorts, N.tile_ctl + kNativeCtlSorts, sizeof(sorts), hipMemcpyDeviceToHost, c->stream));
+        GPE_HIP(c, hipStreamSynchronize(c->stream));
+        out.native_sorts = sorts;
+    }
+    memcpy(info, &out, info->struct_size);
+    return GPE_OK;
 }
 
 gpe_status gpe_set_mode(gpe_ctx *c, uint32_t mode)

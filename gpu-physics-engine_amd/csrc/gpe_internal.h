@@ -251,6 +251,7 @@ struct OnesweepWorkspace {
     uint32_t hist_set = 0;           // which of the two sets of copies that is
 };
 
+constexpr int kNativeCtlSorts = 14;   // tile_ctl word: running count of steps whose radix passes ran (k_native.hip kCtlSorts)
 // Native (N-key sort + LDS cell windows) pipeline state
 struct NativeState {
     bool eligible = false;           // every particle inside the world box, grid small enough, windows not over-dense
@@ -263,7 +264,22 @@ struct NativeState {
     uint32_t *keys = nullptr, *ids = nullptr;       // N each: hash output / sort ping
     uint32_t *keys_b = nullptr, *ids_b = nullptr;   // sort pong
     uint64_t cap = 0;
-    uint16_t *codes = nullptr;       // per particle: cell inside its block | neighbour overlap mask (k_native_hash)
+    uint32_t *codes = nullptr;       // per particle: cell relative to its sorted block | neighbour overlap mask | straggler (k_native_hash)
+    uint32_t *exc_count = nullptr;   // straggler lists: [2][exc_tiles] counts, then [2][exc_tiles][16] entries (one allocation)
+    uint2 *exc_entry = nullptr;
+    uint64_t exc_tiles = 0, exc_cap = 0;
+    int32_t exc_tiles_x = 0, exc_tiles_y = 0;
+    const uint32_t *exc_count_now = nullptr;   // the set the current step's tiles read (NULL: the step sorts anyway)
+    const uint2 *exc_entry_now = nullptr;
+    uint32_t *sorted_key = nullptr;  // per particle: the block key it had when the radix passes last ran (written by their
+                                     // first pass); the sorted ids and the block table describe that grouping
+    bool sort_state_valid = false;   // sorted_key / sorted ids / block table belong to the current particle set and box
+    uint64_t sorted_n = 0;           // ... of this many particles
+    uint32_t step_seq = 0;           // native_prepare_step calls: its parity selects the per-step control words
+    const uint32_t *fresh_word = nullptr;   // tile_ctl word the tiles of the current step read (did the passes run?)
+    uint32_t reason = GPE_REASON_NO_PARTICLES;   // why the native kernels do not run (GPE_REASON_*), NONE when they do
+    uint64_t native_steps = 0, compat_steps = 0, sorts_base = 0;   // (sorts_base: device count at the last memset of tile_ctl)
+    bool always_sort = false;        // GPE_FLAG_SORT_EVERY_STEP (A/B measurements, tests): sort every step as rounds 1-2 did
     int32_t blocks_x = 0, blocks_y = 0;   // 8x8-cell blocks of the block box: table index = (by - by0) * blocks_x + (bx - bx0)
     int32_t bx0 = 0, by0 = 0;        // first block of the box (sharded runs: the rank's active box; else 0, 0)
     uint32_t *tile_ctl = nullptr;    // device control words (k_native.hip kCtl*)
@@ -271,8 +287,8 @@ struct NativeState {
     uint64_t overflow_cap = 0;
     void *arena = nullptr;           // global spill arena for those tiles' particle arrays (37 B per slot)
     uint64_t arena_cap = 0;          // slots
-    bool force = false;              // GPE_NATIVE_FORCE=1 (tests): no hand-over to the compat kernels
-    bool print_stats = false;        // GPE_NATIVE_STATS=1: print the step statistics every 128 steps
+    bool force = false;              // GPE_FLAG_NATIVE_FORCE (tests): no hand-over to the compat kernels
+    bool print_stats = false;        // GPE_FLAG_NATIVE_STATS: print the step statistics every 128 steps
     uint32_t stat_calls = 0;
     uint32_t *host_stat = nullptr;   // pinned, 16 words (k_native.hip kStat*): window maximum, arena use, probe answer, overflow tiles
     uint32_t window_max = 0;         // the same, measured synchronously at configuration time
@@ -432,11 +448,23 @@ VerletParams verlet_params(const gpe_ctx *c, float dt);
 gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n);
 void onesweep_release(gpe_ctx *c);
 gpe_status onesweep_zero_hist(gpe_ctx *c);
+// A sort that the device may skip (the native step, k_native.hip): every pass returns at once when *need == 0.
+// The first pass copies the keys in input order to key_copy and resets the block table (table_pairs uint4 entries),
+// the last one sets *fresh and counts the sort.  Passed by value to the pass kernel.
+struct OnesweepGate {
+    const uint32_t *need = nullptr;
+    uint32_t *key_copy = nullptr;
+    uint4 *table_reset = nullptr;
+    uint64_t table_pairs = 0;
+    uint32_t *fresh = nullptr;
+    uint32_t *sorts = nullptr;
+};
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
                          uint32_t **out_vals, bool bases_ready = false, uint2 *table = nullptr,
                          uint32_t table_entries = 0,    // table: the last pass also fills the native block table
-                         const uint32_t *hist_src = nullptr);   // bases_ready: histogram copies the passes scan themselves
+                         const uint32_t *hist_src = nullptr,   // bases_ready: histogram copies the passes scan themselves
+                         const OnesweepGate *gate = nullptr);
 // native pipeline (k_native.hip)
 gpe_status native_configure(gpe_ctx *c);
 bool native_should_run(gpe_ctx *c);

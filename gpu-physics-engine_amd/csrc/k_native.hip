@@ -88,14 +88,35 @@ constexpr int kCtlSubTiles = 5;                // 16x16 quarters redone as four 
 constexpr int kCtlSpills = 6;                  // 8x8 tiles staged in the global spill arena this step
 constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every step
 constexpr int kCtlError = 8;                   // sticky
+// Two words each, indexed by the parity of the step (native_prepare_step counts them): a step's hash kernel clears
+// the NEXT step's word while its own is being set, so no workgroup of a launch races with another's reset.
+constexpr int kCtlNeedSort = 10;               // [parity] the hash found a particle outside the drift its code can express
+constexpr int kCtlFresh = 12;                  // [parity] the radix passes ran: the block table describes THIS step's positions
+constexpr int kCtlSorts = kNativeCtlSorts;     // steps whose radix passes ran (running count, gpe_get_pipeline_info)
+// How far a particle may have left the 8x8-cell block it was sorted into (cells beyond the block's extent, per
+// direction) and still be found by every tile that needs it.  A tile looks up the blocks of tile +- 8 cells but keeps
+// only the window [x0-5, x1+4] x [y0-3, y1+2] (kCone* + 1): a kept particle that moved right by dr cells comes from a
+// block that starts at >= (x0-5) - 7 - dr, inside the lookup (>= x0-15, block-aligned: x0-8) while dr <= 3; moved left:
+// its block starts at <= x1+4+dl <= x1+8 while dl <= 4; up: >= (y0-3) - 7 - du >= y0-15 while du <= 5; down: <= y1+2+dd
+// <= y1+8 while dd <= 6.  The code keeps the cell relative to the OLD block in 4 + 4 bits: x in [-4, 10], y in [-6, 9].
+constexpr int kDriftLeft = 4, kDriftRight = 3, kDriftDown = 6, kDriftUp = 2;
+// A particle beyond that reach (a straggler: in a cloud without damping a few particles are always fast) does not
+// force a sort by itself: the hash kernel hands it, with its cell, to every 32x32 tile whose cell window holds it
+// (at most four), kExcSlots per tile, and marks its code so that the tiles skip it in the old block's list.  Only a
+// tile's list running over raises kCtlNeedSort.  Two sets of lists, by step parity (reset like the control words).
+constexpr uint32_t kExcSlots = 16;
+constexpr uint32_t kCodeStraggler = 1u << 16;
+static_assert(kDriftRight <= kHalo - (kConeLeft + 1) && kDriftLeft <= kHalo - (kConeRight + 1), "x drift inside the lookup slack");
+static_assert(kDriftUp <= kHalo - (kConeDown + 1) && kDriftDown <= kHalo - (kConeUp + 1), "y drift inside the lookup slack");
+static_assert(kDriftLeft + 8 + kDriftRight <= 16 && kDriftDown + 8 + kDriftUp <= 16, "relative cell fits 4 bits per axis");
 // pinned host words the kernels report to (read by the step policy with a lag of the steps in flight)
 constexpr int kStatWindowMax = 0;              // largest 24x24-cell window population of the last native step
 constexpr int kStatArena = 1;                  // spill-arena slots handed out by the last native step
 constexpr int kStatProbe = 2;                  // window population measured by the last asynchronous probe + 1 (0: none yet)
 constexpr int kStatOverflow = 3;               // 32x32 tiles over capacity in the last native step
 constexpr int kStatSubTiles = 4, kStatSpills = 5;   // quarters redone as 8x8 tiles / 8x8 tiles through the arena (diagnostics)
-constexpr uint64_t kArenaBytesPerSlot = 37;
-constexpr uint64_t kArenaMaxSlots = 1ull << 30; // the arena's slot numbers are 32 bit; 40 GB of the 288 GB    // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
+constexpr uint64_t kArenaBytesPerSlot = 37;     // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
+constexpr uint64_t kArenaMaxSlots = 1ull << 30; // the arena's slot numbers are 32 bit; 40 GB of the 288 GB
 // tile sizes (cells) and LDS capacities (particles staged per region)
 #ifndef GPE_CAP_MAIN
 #define GPE_CAP_MAIN 1192
@@ -177,12 +198,24 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                                                             int32_t bx0, int32_t by0, int32_t blocks_x,
                                                             int32_t blocks_y, uint32_t pad_key,
                                                             uint32_t *__restrict__ keys,
-                                                            uint16_t *__restrict__ codes, int digits,
+                                                            uint32_t *__restrict__ codes, int digits,
                                                             uint32_t *hist4, uint32_t *__restrict__ hist_next,
                                                             uint32_t *__restrict__ os_ctl, uint32_t *tile_ctl,
                                                             uint4 *__restrict__ table2, uint64_t table_pairs,
-                                                            uint32_t *__restrict__ host_stat)
+                                                            uint32_t *__restrict__ host_stat,
+                                                            const uint32_t *__restrict__ sorted_key, uint32_t parity,
+                                                            uint64_t div_magic, uint32_t *__restrict__ exc_count,
+                                                            uint2 *__restrict__ exc_entry,
+                                                            uint32_t *__restrict__ exc_count_next, int32_t exc_tiles_x,
+                                                            int32_t exc_tiles_y)
 {
+    // sorted_key[i] = the block key particle i had when the radix passes last ran (they keep it up to date,
+    // k_onesweep.hip): the sorted ids and the block table still describe THAT grouping.  As long as every particle
+    // is within kDrift* cells of its old block, the tiles find it through the old table (they look up more than they
+    // keep) and this step needs no sort: the code carries the particle's cell RELATIVE to the old block.  Particles
+    // beyond that go to per-tile straggler lists (kExcSlots); a list running over raises tile_ctl[kCtlNeedSort +
+    // parity]; the radix passes that follow look at the word and return at once when it is 0.
+    // sorted_key == NULL: always sort (first step, sharded runs, one-pass sorts).
     __shared__ uint32_t s_hist[4 * 256];
     s_hist[threadIdx.x] = 0;
     // What a step accumulates into is reset here instead of by a launch of its own (a launch costs ~6 us, 5 % of
@@ -192,6 +225,11 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     // this step's set is read by the radix passes that follow, nobody touches the other one meanwhile).
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         table2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);      // (first, one past last) = (max, 0): empty
+    if (exc_count_next) {                                              // the next step's straggler lists
+        const uint64_t nt = (uint64_t)exc_tiles_x * (uint64_t)exc_tiles_y;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (uint64_t)gridDim.x * blockDim.x)
+            exc_count_next[i] = 0;
+    }
     if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords) {
         if (host_stat) {                                               // last step's statistics (kStat*), lagged
             if (threadIdx.x == kCtlWindowMax) host_stat[kStatWindowMax] = tile_ctl[kCtlWindowMax];
@@ -205,6 +243,11 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kHashBlock) hist_next[i] = 0;
         if (threadIdx.x < 8) os_ctl[threadIdx.x] = 0;                  // tile tickets + error word
+        if (threadIdx.x == 0) {                                        // the next step's words; this step's if it must sort
+            tile_ctl[kCtlNeedSort + (parity ^ 1u)] = 0;
+            tile_ctl[kCtlFresh + (parity ^ 1u)] = 0;
+            if (!sorted_key) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
+        }
     }
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -216,24 +259,26 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
         nv = *n_valid_ptr;
         if (nv > n) { nv = n; if (threadIdx.x == 0) atomicOr(&tile_ctl[kCtlError], kErrBoundExceeded); }
     }
-    bool oob = false;
+    bool oob = false, drifted = false;
     for (uint64_t r0 = 0; r0 < rounds; r0 += kHashBatch) {
         float2 p[kHashBatch];
         float rad[kHashBatch];
         uint64_t idx[kHashBatch];
+        uint32_t okey[kHashBatch];
 #pragma unroll
         for (int u = 0; u < kHashBatch; ++u) {                        // the loads of a batch are in flight together
             idx[u] = (r0 + u) * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
             const bool in = r0 + u < rounds && idx[u] < nv;
             p[u] = in ? pos[idx[u]] : make_float2(0.f, 0.f);
             rad[u] = in ? radius[idx[u]] : 0.f;
+            okey[u] = (in && sorted_key) ? sorted_key[idx[u]] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kHashBatch; ++u) {
             if (r0 + u >= rounds) break;                               // wave-uniform
             const bool valid = idx[u] < n;
             uint32_t key = pad_key;
-            if (valid && idx[u] >= nv) { keys[idx[u]] = pad_key; codes[idx[u]] = 0; }
+            if (valid && idx[u] >= nv) { keys[idx[u]] = pad_key; codes[idx[u]] = 0u; }
             if (idx[u] < nv) {
                 const int32_t cx = cell_coord(p[u].x, cell_size), cy = cell_coord(p[u].y, cell_size);
                 // the particle's 8x8-cell block, row-major over the block box (0 for a particle outside it: flagged)
@@ -243,10 +288,36 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 oob |= out;
                 key = out ? 0u : (uint32_t)(lby * blocks_x + lbx);
                 keys[idx[u]] = key;
-                // what the tiles need to file the particle: its cell inside the block and its phantom cells.
+                // The particle's cell relative to the first cell of the block it was SORTED into (== its block of now
+                // when the passes run this step: then the tiles take the value mod 8).  okey / blocks_x by a 64-bit
+                // multiply: exact for okey * blocks_x < 2^40 (keys < 2^27, blocks_x <= 2^13).
+                int32_t relx = cx & 7, rely = cy & 7;
+                bool straggler = false;
+                if (sorted_key) {
+                    const uint32_t oby = (uint32_t)(((uint64_t)okey[u] * div_magic) >> 40);
+                    const uint32_t obx = okey[u] - oby * (uint32_t)blocks_x;
+                    relx = cx - (int32_t)((obx + (uint32_t)bx0) << 3);
+                    rely = cy - (int32_t)((oby + (uint32_t)by0) << 3);
+                    straggler = !out && ((relx < -kDriftLeft) | (relx > 7 + kDriftRight) | (rely < -kDriftDown) | (rely > 7 + kDriftUp));
+                }
+                // what the tiles need to file the particle: that relative cell and its phantom cells.
                 // Computed once here instead of by each of the ~2.25 tiles that stage the particle.
-                codes[idx[u]] = (uint16_t)((uint32_t)(cx & 7) | ((uint32_t)(cy & 7) << 3) |
-                                           (neighbour_overlap_mask(p[u], rad[u], cx, cy, cell_size) << 6));
+                // (A straggler's relative cell is still right mod 8, which is what the tiles use when the passes run.)
+                codes[idx[u]] = ((uint32_t)(relx + kDriftLeft) & 15u) | (((uint32_t)(rely + kDriftDown) & 15u) << 4) |
+                                (neighbour_overlap_mask(p[u], rad[u], cx, cy, cell_size) << 8) | (straggler ? kCodeStraggler : 0u);
+                if (straggler) {
+                    // every 32x32 tile whose window [32 tx - 5, 32 tx + 35] x [32 ty - 3, 32 ty + 33] holds the cell
+                    // (sub-tiles of the over-capacity launch read their parent's list: their windows lie inside its)
+                    const int tx0 = max(0, (cx - (kConeRight + 1)) >> 5), tx1 = min(exc_tiles_x - 1, (cx + kConeLeft + 1) >> 5);
+                    const int ty0 = max(0, (cy - (kConeUp + 1)) >> 5), ty1 = min(exc_tiles_y - 1, (cy + kConeDown + 1) >> 5);
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) {
+                            const uint32_t t = (uint32_t)(ty * exc_tiles_x + tx);
+                            const uint32_t slot = atomicAdd(&exc_count[t], 1u);
+                            if (slot < kExcSlots) exc_entry[(uint64_t)t * kExcSlots + slot] = make_uint2((uint32_t)idx[u], (uint32_t)cx | ((uint32_t)cy << 16));
+                            else drifted = true;                          // a list ran over: sort
+                        }
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -254,6 +325,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
         }
     }
     if (oob) atomicOr(&tile_ctl[kCtlError], kErrOutOfBox);
+    if (__ballot(drifted) != 0 && lane_id() == 0) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
     __syncthreads();
     // Flush: fire-and-forget device-scope atomics (the kernel boundary makes them visible); the radix passes turn the
     // histograms into digit bases themselves (k_os_pass, hist_src), so no workgroup waits for the others here.
@@ -331,7 +403,13 @@ struct CollideArgs {
     const float *radius;
     float2 *pos_out;
     const uint32_t *sorted_ids;
-    const uint16_t *codes;       // per particle: cell inside its block (6 bits) | neighbour overlap mask (8 bits)
+    const uint32_t *codes;       // per particle: cell relative to the block it was sorted into (4 + 4 bits, biased by
+                                 // kDriftLeft / kDriftDown) | neighbour overlap mask (8 bits) | kCodeStraggler
+    const uint32_t *exc_count;   // stragglers handed to each 32x32 tile this step (NULL: none, the run always sorts)
+    const uint2 *exc_entry;      // kExcSlots x (particle, cell x | y << 16) per tile
+    int32_t exc_tiles_x;
+    const uint32_t *fresh;       // tile_ctl[kCtlFresh + parity]: != 0 when the radix passes ran this step (the table's
+                                 // blocks are the particles' blocks of NOW: relative cell = cell inside the block)
     const uint2 *table;
     uint32_t entries;
     int32_t blocks_x, blocks_y;  // table index of block (bx, by) = (by - by0) * blocks_x + (bx - bx0)
@@ -384,9 +462,9 @@ struct TileLds {
     static constexpr bool kLid = LID;
     static constexpr int kSlots = CAP;                 // particles the window keeps
     uint32_t lid[LID ? CAP : 1];
-    // The blocks of tile +- 8 cells are looked up (block granule), but only particles whose home cell lies within
-    // +- 5 cells are kept: 23 % fewer particles in LDS at 32x32, and the window overflows that much later.
-    // The exact cone is not a square (see kConeLeft ...): 5 / 4 cells left / right of the tile, 3 / 2 below / above.
+    // The blocks of tile +- 8 cells are looked up (block granule), but only particles whose home cell lies in the
+    // tile's dependency cone are kept -- 5 / 4 cells left / right of the tile, 3 / 2 below / above (see kConeLeft ...):
+    // a third fewer particles in LDS at 32x32, and the window overflows that much later.
     static constexpr int HXL = kConeLeft + 1, HXR = kConeRight + 1, HYL = kConeDown + 1, HYR = kConeUp + 1;
     static constexpr int RWX = T + HXL + HXR, RWY = T + HYL + HYR;
     // The cell array carries a ring of one cell around the window: a kept particle's phantom cells then always have
@@ -415,7 +493,7 @@ struct TileLds {
     uint32_t id[CAP];
     uint32_t hm[CAP];          // bits 0-10 index of the home cell in the padded cell array; bits 11-18 overlap mask of
                                // the 8 neighbour cells (k_native_hash); bit 19 the home cell lies in the tile (the
-                               // particle is the tile's own); bits 20-30 the particle's slot among the looked-up ones
+                               // particle is the tile's own)
     // cell[lc + 1]: members of cell lc (P1) -> first slot of its list (P2) -> one past its last slot (P3);
     // cell[0] = 0, so from P3 on the list of cell lc is mem[cell[lc] .. cell[lc + 1]).  Values stay below
     // 4 * CAP < 65536: two cells share a word (LDS atomics are 32 bit, so cell_inc adds 1 or 1 << 16 --
@@ -1017,12 +1095,24 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     }
     __syncthreads();
     const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);   // the same in every lane: keep it scalar
-    if (S.misc[1] == 0) return true;                                   // nothing of its own to write
+    // Nothing of its own to write: no particle in the tile's own blocks AND in the ring around them (a particle may have
+    // drifted up to kDrift* cells out of the block the table lists it in, so the own blocks alone do not tell).
+    if (P == 0) return true;
+    // (relative cell -> cell inside the block when the table is of this step: the value mod 8; else unchanged)
+    const bool stale = __builtin_amdgcn_readfirstlane((int)*A.fresh) == 0;
+    const int rel_mask = stale ? -1 : 7;
+    const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;       // (listed under a block it is out of reach of: skipped)
+    // stragglers handed to this tile's 32x32 parent by the hash kernel (P1 files them behind the looked-up particles)
+    uint32_t n_exc = 0;
+    if (stale && A.exc_count) {
+        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
+        n_exc = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.exc_count[pt]), kExcSlots);
+    }
     if constexpr (L::kGlobal) {
         // take a slice of the global spill arena for this tile's particle arrays
         if (tid == 0) {
-            const uint32_t base = atomicAdd(&A.tile_ctl[kCtlArena], P);
-            const bool ok = (uint64_t)base + P <= (uint64_t)A.arena_cap;
+            const uint32_t base = atomicAdd(&A.tile_ctl[kCtlArena], P + kExcSlots);     // (+ the stragglers' slots)
+            const bool ok = (uint64_t)base + P + kExcSlots <= (uint64_t)A.arena_cap;
             S.misc[2] = ok ? 1u : 0u;
             S.px = A.arena_px + base; S.py = A.arena_py + base; S.rad = A.arena_rad + base;
             S.id = A.arena_id + base; S.hm = A.arena_hm + base; S.sblk = A.arena_sblk + base;
@@ -1059,7 +1149,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             // Branch-free on purpose: behind `if (s < P)` hipcc merges the loaded value with the default through
             // register copies that wait for the load (s_waitcnt vmcnt(0) right behind it), so the rounds' loads ran one
             // after the other -- three dependent global round trips.  Slots beyond P re-read slot P - 1 (a cache hit)
-            // and are discarded by `keep` below.  (P >= 1: the tile has particles of its own.)
+            // and are discarded by `keep` below.  (P >= 1: see P0.)
             const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * kNatThreads, P - 1u);
             blk[q] = S.sblk[s];
             pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
@@ -1095,9 +1185,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            lxq[q] = (int)(blk[q] % NB) * 8 + (int)(cc[q] & 7u) - (kHalo - HX);
-            lyq[q] = (int)(blk[q] / NB) * 8 + (int)((cc[q] >> 3) & 7u) - (kHalo - HY);
-            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY;
+            lxq[q] = (int)(blk[q] % NB) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
+            lyq[q] = (int)(blk[q] / NB) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
+            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
             slot[q] = s;
         }
         if constexpr (kTrim) {
@@ -1118,6 +1208,17 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         }
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
+            if constexpr (!kTrim) {
+                // The spill window's slots are the looked-up slots: a particle that has drifted out of the looked-up
+                // region (it is listed under its old block) still owns one.  File it under ring cell 0 -- outside every
+                // colour's zone, never walked, never written back -- so that the loops over the slots find a valid entry.
+                if (!keep[q] && s0 + (uint32_t)tid + (uint32_t)q * kNatThreads < P) {
+                    const uint32_t s = slot[q];
+                    S.px[s] = pp[q].x; S.py[s] = pp[q].y; S.rad[s] = pr[q]; S.id[s] = pid[q];
+                    S.cell_inc(0 + 1);
+                    S.hm[s] = 0u;
+                }
+            }
             if (!keep[q]) continue;
             const uint32_t s = slot[q];
             const int lx = lxq[q], ly = lyq[q];
@@ -1126,7 +1227,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const int home = (ly + 1) * PX + lx + 1;                  // index in the padded cell array
             S.cell_inc(home + 1);
             // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
-            uint32_t over = (cc[q] >> 6) & 0xFFu;
+            uint32_t over = (cc[q] >> 8) & 0xFFu;
             const uint32_t own = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? (1u << 19) : 0u;
             S.hm[s] = (uint32_t)home | (over << 11) | own;
 #pragma unroll
@@ -1138,14 +1239,58 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             }
         }
     }
+    if (n_exc != 0 && tid < 64) {                                      // (scalar condition; one wave files them)
+        // Stragglers: particles out of reach of the block the table lists them under, handed over with their cell.
+        const bool have = (uint32_t)tid < n_exc;
+        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
+        const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + (have ? (uint32_t)tid : 0u)];
+        uint32_t pid = en.x;
+        const float2 pp = A.pos_in[pid];
+        const float pr = A.radius[pid];
+        const uint32_t cc = A.codes[pid];
+        const uint32_t lidq = pid;
+        if constexpr (ORD) pid = A.order_keys[pid];
+        const int lx = (int)(en.y & 0xFFFFu) - ox, ly = (int)(en.y >> 16) - oy;
+        bool keep = have && lx >= 0 && lx < RWX && ly >= 0 && ly < RWY;
+        uint32_t sl = P + (uint32_t)tid;                               // the spill window: slots behind the looked-up ones
+        if constexpr (kTrim) {
+            const uint64_t mk = __ballot(keep);
+            uint32_t base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            sl = base + popc_below_lane(mk);
+            keep = keep && sl < (uint32_t)(sizeof(S.px) / sizeof(float));
+        } else if (have && !keep) {
+            S.px[sl] = pp.x; S.py[sl] = pp.y; S.rad[sl] = pr; S.id[sl] = pid;
+            S.cell_inc(0 + 1);
+            S.hm[sl] = 0u;
+        }
+        if (keep) {
+            S.px[sl] = pp.x; S.py[sl] = pp.y; S.rad[sl] = pr; S.id[sl] = pid;
+            if constexpr (L::kLid) S.lid[sl] = lidq;
+            const int home = (ly + 1) * PX + lx + 1;
+            S.cell_inc(home + 1);
+            uint32_t over = (cc >> 8) & 0xFFu;
+            const uint32_t own = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? (1u << 19) : 0u;
+            S.hm[sl] = (uint32_t)home | (over << 11) | own;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (over == 0) break;
+                const int k = __ffs((int)over) - 1;
+                over &= over - 1u;
+                S.cell_inc(home + neighbour_offset<PX>(k) + 1);
+            }
+        }
+    }
     __syncthreads();
     GPE_STAMP(1);
     // particles in the window from here on: the kept ones (the global window keeps every looked-up particle: its
-    // cell window is the looked-up blocks)
-    uint32_t PS = P;
+    // cell window is the looked-up blocks; the stragglers sit behind them)
+    uint32_t PS = P + (kTrim ? 0u : n_exc);
     if constexpr (kTrim) {
         PS = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[3]);
         if (PS > (uint32_t)(sizeof(S.px) / sizeof(float))) return false;    // more kept particles than the window stages
+        if (PS == 0) return true;                                      // (looked up, none inside the window)
     }
 
     // ---- P2: exclusive scan of the per-cell counts -> list starts ----------------------------------
@@ -1204,7 +1349,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             own_id[q] = 0xFFFFFFFFu;
             fetch[q] = 0u;
             if (q >= 2 && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar: the third round is nearly always empty)
-            const uint32_t sc = min(s, PS - 1u);                       // PS >= 1: the tile has particles of its own
+            const uint32_t sc = min(s, PS - 1u);                       // PS >= 1 (checked behind P1)
             const uint32_t hm = S.hm[sc];
             const bool own = s < PS && (hm & (1u << 19)) != 0;
             uint32_t id = S.id[sc];
@@ -1546,6 +1691,8 @@ void native_release(gpe_ctx *c)
     if (N.block_table) (void)hipFree(N.block_table);
     if (N.keys) (void)hipFree(N.keys);
     if (N.codes) (void)hipFree(N.codes);
+    if (N.sorted_key) (void)hipFree(N.sorted_key);
+    if (N.exc_count) (void)hipFree(N.exc_count);
     if (N.ids) (void)hipFree(N.ids);
     if (N.keys_b) (void)hipFree(N.keys_b);
     if (N.ids_b) (void)hipFree(N.ids_b);
@@ -1558,8 +1705,14 @@ void native_release(gpe_ctx *c)
 
 static gpe_status arena_reserve(gpe_ctx *c, uint64_t want);
 
-// hash -> sort -> block table.  *sorted_ids receives the particle ids in Morton order of their home cell.
-static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
+// hash -> [sort -> block table].  *sorted_ids receives the particle ids grouped by 8x8-cell block.
+// The radix passes are enqueued every step but run only when the hash kernel finds a particle that has left the
+// reach of the grouping they last produced (kDrift* cells beyond its block): the sorted ids and the block table are
+// kept across steps, the per-particle codes say where each particle is relative to its old block, and the tiles look up
+// more blocks than they keep particles from.  Decided on the device, step by step; the host waits for nothing.
+// In the benchmark cloud (gravity off) a sort is needed every few dozen steps, in free fall every 5-25 steps.
+// always_sort: this call must not rely on the kept grouping (configuration-time probes).
+static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool always_sort = false)
 {
     NativeState &N = c->native;
     const uint64_t n = c->n;
@@ -1572,16 +1725,26 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
     uint32_t *hist_now = c->os_ws.hist4 + (size_t)c->os_ws.hist_set * kHistSet;
     uint32_t *hist_next = c->os_ws.hist4 + (size_t)(c->os_ws.hist_set ^ 1u) * kHistSet;
     c->os_ws.hist_set ^= 1u;
+    const uint32_t parity = (N.step_seq++) & 1u;
+    // The kept grouping can be used when it belongs to these particles and this box.  Sharded runs (ghosts come and go
+    // every step, padding keys) and one-pass sorts (the table would be reset and filled by the same launch) always sort.
+    const bool sharded = c->shard.on || c->use_order_keys || c->has_active_box;
+    const bool gated = N.passes >= 2 && !sharded;
+    const bool reuse = gated && !always_sort && N.sort_state_valid && N.sorted_n == n && !N.always_sort;
+    const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;        // the table is allocated in 16-byte units
     {
         Scope s(c, "native/hash");
-        const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;    // the table is allocated in 16-byte units
         // at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
         const int grid = (int)std::min<uint64_t>(kHashGridMax, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
         const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr;
+        const uint64_t div_magic = ((1ull << 40) + (uint64_t)N.blocks_x - 1) / (uint64_t)N.blocks_x;
         hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
                            c->cell_size, N.gx, N.gy, N.bx0, N.by0, N.blocks_x, N.blocks_y, N.table_entries, N.keys,
                            N.codes, N.passes, hist_now, hist_next, c->os_ws.ctl, N.tile_ctl,
-                           (uint4 *)N.block_table, pairs, N.host_stat);
+                           (uint4 *)N.block_table, gated ? 0ull : pairs,    // gated: the first radix pass resets the table
+                           N.host_stat, reuse ? N.sorted_key : nullptr, parity, div_magic,
+                           N.exc_count + (size_t)parity * N.exc_tiles, N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots,
+                           N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles, N.exc_tiles_x, N.exc_tiles_y);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
@@ -1589,10 +1752,20 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids)
         // the last radix pass also fills the block table (first / one-past-last position of every block, by
         // atomic min / max at the ends of each tile's key runs); every pass derives its digit bases from hist_now
         Scope s(c, "native/sort");
+        OnesweepGate g;
+        g.need = N.tile_ctl + kCtlNeedSort + parity;
+        g.fresh = N.tile_ctl + kCtlFresh + parity;
+        g.sorts = N.tile_ctl + kCtlSorts;
+        if (gated) { g.key_copy = N.sorted_key; g.table_reset = (uint4 *)N.block_table; g.table_pairs = pairs; }
         GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv, true,
-                              N.block_table, N.table_entries, hist_now));
+                              N.block_table, N.table_entries, hist_now, &g));
     }
     (void)sk;
+    N.sort_state_valid = gated;           // (the passes of this call ran, or the kept state was and stays valid)
+    N.sorted_n = n;
+    N.fresh_word = N.tile_ctl + kCtlFresh + parity;
+    N.exc_count_now = reuse ? N.exc_count + (size_t)parity * N.exc_tiles : nullptr;
+    N.exc_entry_now = N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots;
     *sorted_ids = sv;
     return GPE_OK;
 }
@@ -1608,10 +1781,14 @@ gpe_status native_configure(gpe_ctx *c)
     N.in_box = false;
     N.dense_hold = false;
     N.steps_since_check = 0;
+    N.sort_state_valid = false;          // particles, box or keys changed: the kept grouping is of something else
+    N.always_sort = (c->cfg.flags & GPE_FLAG_SORT_EVERY_STEP) != 0;
+    N.reason = GPE_REASON_NO_PARTICLES;
     if (c->n == 0 || !(c->cell_size > 0.0f)) return GPE_OK;
     // largest home coordinate a clamped particle can take: floor(world / cell_size)
     // (K12 clamps to [r, world - r], particle_integration.wgsl:70-71)
     const float fx = floorf(c->cfg.world_width / c->cell_size), fy = floorf(c->cfg.world_height / c->cell_size);
+    N.reason = GPE_REASON_GRID_TOO_WIDE;
     if (!(fx >= 0.0f) || !(fy >= 0.0f) || fx > 65000.0f || fy > 65000.0f) return GPE_OK;   // 16-bit cell coords
     N.gx = (int32_t)fx + 1;
     N.gy = (int32_t)fy + 1;
@@ -1639,6 +1816,7 @@ gpe_status native_configure(gpe_ctx *c)
     while (bits < 32 && (max_key >> bits) != 0) ++bits;
     N.passes = (bits + 7) / 8;
     if (N.passes < 1) N.passes = 1;
+    N.reason = GPE_REASON_TABLE_TOO_LARGE;
     if (N.table_entries > (1u << 27)) return GPE_OK;                   // > 1 GiB of table: stay on compat
     if (N.table_cap < N.table_entries) {
         if (N.block_table) GPE_HIP(c, hipFree(N.block_table));
@@ -1655,10 +1833,29 @@ gpe_status native_configure(gpe_ctx *c)
         }
         if (N.codes) GPE_HIP(c, hipFree(N.codes));
         N.codes = nullptr;
-        GPE_HIP(c, hipMalloc((void **)&N.codes, (c->cap + 16) * sizeof(uint16_t)));
+        GPE_HIP(c, hipMalloc((void **)&N.codes, (c->cap + 16) * sizeof(uint32_t)));
+        if (N.sorted_key) GPE_HIP(c, hipFree(N.sorted_key));
+        N.sorted_key = nullptr;
+        GPE_HIP(c, hipMalloc((void **)&N.sorted_key, (c->cap + 16) * sizeof(uint32_t)));
         N.cap = c->cap;
     }
     const uint64_t tiles = (uint64_t)((N.gx + kTileMain - 1) / kTileMain) * ((N.gy + kTileMain - 1) / kTileMain);
+    {
+        // straggler lists: per 32x32 tile of the cell box a count and kExcSlots entries, two sets (step parity)
+        N.exc_tiles_x = (N.gx + 31) / 32;
+        N.exc_tiles_y = (N.gy + 31) / 32;
+        N.exc_tiles = (uint64_t)N.exc_tiles_x * (uint64_t)N.exc_tiles_y;
+        if (N.exc_cap < N.exc_tiles) {
+            if (N.exc_count) GPE_HIP(c, hipFree(N.exc_count));
+            N.exc_count = nullptr; N.exc_entry = nullptr; N.exc_cap = 0;
+            const size_t bytes = 2 * N.exc_tiles * sizeof(uint32_t) + 16 + 2 * N.exc_tiles * kExcSlots * sizeof(uint2);
+            GPE_HIP(c, hipMalloc((void **)&N.exc_count, bytes));
+            N.exc_cap = N.exc_tiles;
+        }
+        // (entries behind the counts of both sets, 8-byte aligned)
+        N.exc_entry = (uint2 *)(N.exc_count + ((2 * N.exc_tiles + 1) & ~1ull));
+        GPE_HIP(c, hipMemsetAsync(N.exc_count, 0, 2 * N.exc_tiles * sizeof(uint32_t), c->stream));
+    }
     if (N.overflow_cap < tiles) {
         if (N.overflow1) GPE_HIP(c, hipFree(N.overflow1));
         N.overflow1 = nullptr; N.overflow_cap = 0;
@@ -1671,11 +1868,14 @@ gpe_status native_configure(gpe_ctx *c)
         const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, 1ull << 20), 32ull << 20);
         GPE_TRY(arena_reserve(c, std::max<uint64_t>(want, N.arena_cap)));
     }
-    if (!N.tile_ctl) GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, 64));
+    if (!N.tile_ctl) {
+        GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, 64));
+        GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
+    }
     if (!N.host_stat) GPE_HIP(c, hipHostMalloc((void **)&N.host_stat, 64, hipHostMallocDefault));
     memset(N.host_stat, 0, 64);
     GPE_TRY(onesweep_reserve(c, c->cap));
-    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, kCtlSorts * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kStreamBlock), 0, c->stream, c->pos, c->n,
                        (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr, c->cell_size, N.gx, N.gy,
                        N.tile_ctl + kCtlError);
@@ -1683,14 +1883,15 @@ gpe_status native_configure(gpe_ctx *c)
     uint32_t flag = 1;
     GPE_HIP(c, hipMemcpyAsync(&flag, N.tile_ctl + kCtlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
-    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));         // the check's verdict is not a step error
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, kCtlSorts * sizeof(uint32_t), c->stream));         // the check's verdict is not a step error
+    N.reason = GPE_REASON_OUT_OF_BOX;
     if (flag != 0) return GPE_OK;                                      // a particle outside the box: compat kernels
     N.in_box = true;
     // window population of the current state
     const bool prof = c->profiling;
     c->profiling = false;
     uint32_t *ids = nullptr;
-    gpe_status st = native_prepare_step(c, &ids);
+    gpe_status st = native_prepare_step(c, &ids, true);
     c->profiling = prof;
     GPE_TRY(st);
     hipLaunchKernelGGL(k_native_window_max, dim3(stream_grid(N.table_entries)), dim3(kStreamBlock), 0, c->stream,
@@ -1699,15 +1900,15 @@ gpe_status native_configure(gpe_ctx *c)
     uint32_t wmax = 0xffffffffu;
     GPE_HIP(c, hipMemcpyAsync(&wmax, N.tile_ctl + kCtlWindowMax, sizeof(wmax), hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
-    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
+    GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, kCtlSorts * sizeof(uint32_t), c->stream));
     N.window_max = wmax;
     N.eligible = wmax <= kWindowEligible;
-    // test hook: keep over-dense scenes on the native kernels (their windows then go through the spill arena)
-    const char *force = getenv("GPE_NATIVE_FORCE");
-    N.force = force && force[0] == '1';
-    const char *stats = getenv("GPE_NATIVE_STATS");                    // diagnostics: print the step statistics every 128 steps
-    N.print_stats = stats && stats[0] == '1';
-    if (N.force) N.eligible = true;
+    N.reason = N.eligible ? GPE_REASON_NONE : GPE_REASON_DENSE_WINDOWS;
+    // gpe_config.flags: keep over-dense scenes on the native kernels (their windows then go through the spill arena);
+    // print the step statistics every 128 steps; sort every step
+    N.force = (c->cfg.flags & GPE_FLAG_NATIVE_FORCE) != 0;
+    N.print_stats = (c->cfg.flags & GPE_FLAG_NATIVE_STATS) != 0;
+    if (N.force) { N.eligible = true; N.reason = GPE_REASON_NONE; }
     return GPE_OK;
 }
 
@@ -1717,13 +1918,16 @@ static gpe_status arena_reserve(gpe_ctx *c, uint64_t want)
 {
     NativeState &N = c->native;
     if (N.arena_cap >= want) return GPE_OK;
-    GPE_HIP(c, hipStreamSynchronize(c->stream));
-    if (N.arena) GPE_HIP(c, hipFree(N.arena));
-    N.arena = nullptr; N.arena_cap = 0;
-    hipError_t e = hipMalloc(&N.arena, want * kArenaBytesPerSlot + 256);
+    // the new arena first: on failure the old one stays in place (a run that must stay on the native kernels keeps
+    // working with it) and the error is the caller's to report
+    void *fresh = nullptr;
+    hipError_t e = hipMalloc(&fresh, want * kArenaBytesPerSlot + 256);
     if (e != hipSuccess) (void)hipGetLastError();
     if (e == hipErrorOutOfMemory) return fail(c, GPE_ERR_OOM, "native collide: out of device memory for the spill arena");
     if (e != hipSuccess) return fail(c, GPE_ERR_HIP, std::string("hipMalloc (spill arena): ") + hipGetErrorName(e));
+    GPE_HIP(c, hipStreamSynchronize(c->stream));                       // (kernels in flight may still use the old one)
+    if (N.arena) GPE_HIP(c, hipFree(N.arena));
+    N.arena = fresh;
     N.arena_cap = want;
     return GPE_OK;
 }
@@ -1738,7 +1942,7 @@ static gpe_status native_probe_async(gpe_ctx *c)
     const bool prof = c->profiling;
     c->profiling = false;
     uint32_t *ids = nullptr;
-    const gpe_status st = native_prepare_step(c, &ids);
+    const gpe_status st = native_prepare_step(c, &ids, true);
     c->profiling = prof;
     GPE_TRY(st);
     hipLaunchKernelGGL(k_native_window_max, dim3(stream_grid(N.table_entries)), dim3(kStreamBlock), 0, c->stream,
@@ -1765,15 +1969,18 @@ bool native_should_run(gpe_ctx *c)
                         "quarters redone as 8x8 tiles %u, 8x8 tiles through the arena %u\n", N.stat_calls,
                 N.host_stat[kStatWindowMax], N.host_stat[kStatArena], (unsigned long long)N.arena_cap,
                 N.host_stat[kStatOverflow], N.host_stat[kStatSubTiles], N.host_stat[kStatSpills]);
-    if (!N.eligible && must_stay && N.in_box) { N.eligible = true; N.dense_hold = false; }   // density alone never stops such a run
+    if (!N.eligible && must_stay && N.in_box) { N.eligible = true; N.dense_hold = false; N.reason = GPE_REASON_NONE; }   // density alone never stops such a run
     if (N.eligible) {
         if (N.host_stat && (uint64_t)N.host_stat[kStatArena] * 2 > N.arena_cap && N.arena_cap < kArenaMaxSlots) {
-            if (arena_reserve(c, std::min<uint64_t>(N.arena_cap * 2, kArenaMaxSlots)) != GPE_OK) return false;
+            // (on failure the old arena stays and the step goes on with it: a window it cannot hold raises
+            // kErrTileOverflow, which gpe_sync reports -- never a silent hand-over of a run that must stay native)
+            if (arena_reserve(c, std::min<uint64_t>(N.arena_cap * 2, kArenaMaxSlots)) != GPE_OK && !must_stay) return false;
             N.host_stat[kStatArena] = 0;
         }
         if (!must_stay && N.host_stat && N.host_stat[kStatWindowMax] > kWindowHandover) {
             N.eligible = false;
             N.dense_hold = true;
+            N.reason = GPE_REASON_DENSE_WINDOWS;
             N.steps_since_check = 0;
             N.host_stat[kStatProbe] = 0;
         }
@@ -1784,6 +1991,7 @@ bool native_should_run(gpe_ctx *c)
         if (probe != 0 && probe - 1u <= kWindowHandover * 3 / 4) {    // the last probe found the windows thin again
             N.dense_hold = false;
             N.eligible = true;
+            N.reason = GPE_REASON_NONE;
             N.host_stat[kStatWindowMax] = probe - 1u;
             N.host_stat[kStatProbe] = 0;
             return true;
@@ -1809,6 +2017,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.pos_out = pos_out;
     A.sorted_ids = sorted_ids;
     A.codes = N.codes;
+    A.fresh = N.fresh_word;
+    A.exc_count = N.exc_count_now;
+    A.exc_entry = N.exc_entry_now;
+    A.exc_tiles_x = N.exc_tiles_x;
     A.table = N.block_table;
     A.entries = N.table_entries;
     A.blocks_x = N.blocks_x;

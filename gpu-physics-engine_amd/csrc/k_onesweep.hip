@@ -148,8 +148,13 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
                                                        uint32_t shift, uint32_t pass,
                                                        const uint32_t *__restrict__ bases4, u64 *status,
                                                        uint32_t *ctl, uint32_t epoch, uint2 *table,
-                                                       uint32_t table_entries, const uint32_t *__restrict__ hist_src)
+                                                       uint32_t table_entries, const uint32_t *__restrict__ hist_src,
+                                                       OnesweepGate G)
 {
+    // Gated sort (the native step): the producer of the keys decides on the device whether this sort is needed at all
+    // (k_native_hash: has any particle left the reach of the old block table?).  The passes are enqueued every step
+    // and return here when the word is 0 -- the host never waits for the decision.
+    if (G.need && *G.need == 0u) return;
     constexpr int kOsItems = ITEMS, kOsTile = kOsBlock * ITEMS, kOsWaveSpan = 64 * ITEMS;   // shadow the defaults
     __shared__ uint32_t s_stage[kOsTile];
     __shared__ uint32_t s_whist[kOsWaves][256];
@@ -182,6 +187,21 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
         key[k] = valid ? keys_in[idx] : 0xffffffffu;
         if (IOTA) val[k] = (uint32_t)idx;
         else val[k] = valid ? vals_in[idx] : 0u;
+    }
+    if (G.key_copy) {
+        // first pass of a gated sort: the keys in input order are what the NEXT steps compare against (the block every
+        // particle is being sorted into), and the block table the last pass fills is reset here, a launch earlier
+#pragma unroll
+        for (int k = 0; k < kOsItems; ++k) {
+            const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
+            if (idx < n) G.key_copy[idx] = key[k];
+        }
+        for (uint64_t i = (uint64_t)tile * kOsBlock + threadIdx.x; i < G.table_pairs; i += (uint64_t)gridDim.x * kOsBlock)
+            G.table_reset[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);   // (first, one past last) = (max, 0): empty
+    }
+    if (G.fresh && tile == 0 && threadIdx.x == 0) {                  // last pass: the table is of this step
+        *G.fresh = 1u;
+        atomicAdd(G.sorts, 1u);
     }
     // hist_src (the native step): the producer of the keys left the digit histograms (kHistCopies copies) and no
     // bases -- every tile sums and scans its pass's 256 bins itself, the loads in flight beside the keys'.  That takes
@@ -435,7 +455,7 @@ gpe_status onesweep_zero_hist(gpe_ctx *c)
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,
                          uint32_t **out_vals, bool bases_ready, uint2 *table, uint32_t table_entries,
-                         const uint32_t *hist_src)
+                         const uint32_t *hist_src, const OnesweepGate *gate)
 {
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
@@ -470,9 +490,15 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
         const auto kern = small ? (iota ? k_os_pass<true, kOsItemsSmall> : k_os_pass<false, kOsItemsSmall>)
                                 : (iota ? k_os_pass<true, kOsItems> : k_os_pass<false, kOsItems>);
         const bool last = p == passes - 1;
+        OnesweepGate g;                                            // (all NULL: an ordinary sort)
+        if (gate) {
+            g.need = gate->need;
+            if (p == 0) { g.key_copy = gate->key_copy; g.table_reset = gate->table_reset; g.table_pairs = gate->table_pairs; }
+            if (last) { g.fresh = gate->fresh; g.sorts = gate->sorts; }
+        }
         hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb, vb, n,
                            (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl, ws.epoch,
-                           last ? table : nullptr, table_entries, (hist_ready && bases_ready) ? hist_src : nullptr);
+                           last ? table : nullptr, table_entries, (hist_ready && bases_ready) ? hist_src : nullptr, g);
         GPE_HIP(c, hipGetLastError());
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;

@@ -31,16 +31,18 @@ def _ptr(a):
 class Context:
     """WgpuContext::new_for_test() stand-in (wgpu_context.rs:73-101): device + queue == HIP stream."""
 
-    def __init__(self, world=(3048.0, 1048.0), gravity=(0.0, 0.0), mode=L.MODE_COMPAT, device=-1,
-                 profiling=False, stream=None):
+    def __init__(self, world=(3048.0, 1048.0), gravity=(0.0, 0.0), mode=None, device=-1,
+                 profiling=False, stream=None, flags=0):
         self.lib = L.load()
         cfg = L.GpeConfig()
         L.check(self.lib.gpe_config_default(C.byref(cfg)))
         cfg.device = device
         cfg.world_width, cfg.world_height = world
         cfg.gravity_x, cfg.gravity_y = gravity
-        cfg.mode = mode
+        if mode is not None:            # default: gpe_config_default's (NATIVE)
+            cfg.mode = mode
         cfg.profiling = int(profiling)
+        cfg.flags = int(flags)          # L.FLAG_*
         h = C.c_void_p()
         L.check(self.lib.gpe_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -73,6 +75,13 @@ class Context:
 
     def sync(self):
         self.call("gpe_sync")
+
+    def pipeline_info(self):
+        """gpe_get_pipeline_info: which kernels the next step runs (L.PIPELINE_*), why (L.REASON_*), and the counts."""
+        info = L.GpePipelineInfo()
+        info.struct_size = C.sizeof(L.GpePipelineInfo)
+        self.call("gpe_get_pipeline_info", C.byref(info))
+        return {k: getattr(info, k) for k, _ in L.GpePipelineInfo._fields_ if k not in ("struct_size", "reserved")}
 
     def download(self, what, dtype, shape=None):
         nbytes = C.c_uint64()
@@ -329,10 +338,10 @@ class PrefixSum:
 class State:
     """state.rs:21-31 without window/renderer: particles + grid + collision system and update()."""
 
-    def __init__(self, positions, radii, world=(3048.0, 1048.0), gravity=(0.0, 0.0), mode=L.MODE_COMPAT,
-                 prev=None, device=-1, profiling=False):
+    def __init__(self, positions, radii, world=(3048.0, 1048.0), gravity=(0.0, 0.0), mode=None,
+                 prev=None, device=-1, profiling=False, flags=0):
         self.world, self.gravity, self.mode = tuple(map(float, world)), tuple(map(float, gravity)), mode
-        self.ctx = Context(world=world, gravity=gravity, mode=mode, device=device, profiling=profiling)
+        self.ctx = Context(world=world, gravity=gravity, mode=mode, device=device, profiling=profiling, flags=flags)
         self.particles = ParticleSystem.new_from_buffers(self.ctx, positions, radii, prev=prev)
         self.grid = Grid(self.ctx, self.particles)
         self.collision_system = CollisionSystem(self.ctx, 2, self.particles, self.grid)
@@ -365,7 +374,7 @@ class State:
                  radius=self.radii(), world=np.array(self.world, np.float32), gravity=np.array(self.gravity, np.float32))
 
     @classmethod
-    def load(cls, path, mode=L.MODE_COMPAT, device=-1):
+    def load(cls, path, mode=None, device=-1):
         """A State that continues from a snapshot written by save(): the next update() yields the same bits as
         the saved run's next update() would have (the step has no hidden state beyond these arrays)."""
         with np.load(path, allow_pickle=False) as d:

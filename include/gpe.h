@@ -65,8 +65,20 @@ typedef struct gpe_config {
     float    mouse_strength;       /* particle_integration.wgsl:22  = 150                     */
     uint32_t mode;                 /* GPE_MODE_*                                              */
     uint32_t profiling;            /* as gpe_set_profiling: 0 off, 1 every scope, k every k-th step */
-    uint32_t reserved[5];
+    uint32_t flags;                /* GPE_FLAG_* (0 = the defaults); was reserved[0]          */
+    uint32_t reserved[4];
 } gpe_config;
+
+/* gpe_config.flags -- switches for tests and measurements; the reference has no counterpart (state.rs:34-70 builds one
+ * pipeline).  None of them changes a result bit. */
+enum {
+    GPE_FLAG_NATIVE_FORCE = 1u,      /* never hand an over-dense scene to the COMPAT kernels (windows then spill)   */
+    GPE_FLAG_SORT_EVERY_STEP = 2u,   /* NATIVE: run the radix passes every step instead of when a particle has left */
+                                     /* the reach of the kept block table (what rounds 1-2 did; for A/B timing)     */
+    GPE_FLAG_NATIVE_STATS = 4u,      /* print the tile statistics to stderr every 128 steps                          */
+    GPE_FLAG_SAFE_SORT = 8u          /* per-module sorts by the communication-free reduce-then-scan radix sort       */
+                                     /* (k_radix_sort.hip) instead of onesweep: an in-GPU cross-check                */
+};
 
 /* Fills *cfg with the reference's compile-time constants. */
 gpe_status gpe_config_default(gpe_config *cfg);
@@ -132,6 +144,33 @@ gpe_status gpe_step(gpe_ctx *ctx, float dt, uint32_t flags);
 gpe_status gpe_run(gpe_ctx *ctx, float dt, uint64_t steps, uint64_t resort_every, int32_t resort_first);
 gpe_status gpe_sync(gpe_ctx *ctx);
 gpe_status gpe_set_mode(gpe_ctx *ctx, uint32_t mode);
+
+/* Which kernels does the next gpe_step() run, and if not the NATIVE ones, why not?  The reference has one pipeline
+ * and no switch (state.rs:34-70); here mode NATIVE (the default) falls back to the COMPAT kernels -- same bits -- for
+ * the inputs listed below, and this call is how a host sees it.  Synchronises (it reads a device counter). */
+enum { GPE_PIPELINE_COMPAT = 0, GPE_PIPELINE_NATIVE = 1 };
+enum {
+    GPE_REASON_NONE = 0,             /* the NATIVE kernels run                                                     */
+    GPE_REASON_MODE_COMPAT = 1,      /* gpe_config.mode / gpe_set_mode asked for COMPAT                            */
+    GPE_REASON_NO_PARTICLES = 2,     /* nothing to step yet                                                        */
+    GPE_REASON_OUT_OF_BOX = 3,       /* a particle lay outside [0, world] when the context was configured          */
+    GPE_REASON_GRID_TOO_WIDE = 4,    /* more than 65000 cells along an axis (16-bit cell coordinates)              */
+    GPE_REASON_TABLE_TOO_LARGE = 5,  /* more than 2^27 8x8-cell blocks (a block table above 1 GiB)                 */
+    GPE_REASON_DENSE_WINDOWS = 6     /* a 24x24-cell window holds more than 16384 particles (24576 to enter): held */
+                                     /* on COMPAT, probed every 256 steps, returns by itself when it thins out     */
+};
+typedef struct gpe_pipeline_info {
+    uint32_t struct_size;        /* in: sizeof(gpe_pipeline_info)                                                  */
+    uint32_t pipeline;           /* GPE_PIPELINE_*: what the next step runs                                        */
+    uint32_t reason;             /* GPE_REASON_*                                                                   */
+    uint32_t sort_passes;        /* NATIVE: 8-bit radix passes of one sort of the block keys                       */
+    uint64_t native_steps;       /* steps run on the NATIVE kernels since gpe_create                               */
+    uint64_t compat_steps;       /* ... on the COMPAT kernels                                                      */
+    uint64_t native_sorts;       /* NATIVE steps whose radix passes ran (the others reused the kept block table)   */
+    uint32_t window_max;         /* largest 24x24-cell window population last reported by the tiles                */
+    uint32_t reserved;
+} gpe_pipeline_info;
+gpe_status gpe_get_pipeline_info(gpe_ctx *ctx, gpe_pipeline_info *info);
 
 /* ---- downloads (GpuBuffer::download, utils/gpu_buffer.rs:96-175) ---------------------------- */
 typedef enum gpe_array {

@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gpe = importlib.import_module("gpu-physics-engine_amd")
 n = int(sys.argv[1]); steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 grav = (0.0, -9.81) if (len(sys.argv) > 3 and sys.argv[3] == "on") else (0.0, 0.0)
+flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # gpe_config.flags, e.g. 2 = GPE_FLAG_SORT_EVERY_STEP
 world = gpe.scenes.world_for(n)
 pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
-st = gpe.State(pos, rad, world=world, gravity=grav, mode=gpe.MODE_NATIVE)
+st = gpe.State(pos, rad, world=world, gravity=grav, mode=gpe.MODE_NATIVE, flags=flags)
 st.run(1 / 60, 10, resort_every=240, resort_first=True)
 st.ctx.sync()
 t0 = time.perf_counter()
@@ -18,5 +19,7 @@ st.run(1 / 60, steps, resort_every=240, resort_first=False)
 st.ctx.sync()
 tim = st.ctx.timings()
 tag = " ".join("%s=%s" % (k, os.environ[k]) for k in sorted(os.environ) if k.startswith("GPE_"))
+pi = st.ctx.pipeline_info()
+tag += " flags=%d sorts %d of %d steps" % (flags, pi["native_sorts"], pi["native_steps"])
 print("n=%d %s  wall %.4f ms/step | " % (n, tag, wall) +
       "  ".join("%s %.1fus" % (k, v[0] / max(1, v[1]) * 1e3) for k, v in sorted(tim.items(), key=lambda kv: -kv[1][0])), flush=True)

@@ -44,6 +44,9 @@ def test_config_defaults_are_the_reference_constants(gpe):
     assert abs(cfg.stiffness - 0.6) < 1e-7                                   # collision_solver.wgsl:2
     assert cfg.mouse_strength == 150.0                                       # particle_integration.wgsl:22
     assert gpe._lib.load().gpe_compute_cell_size(10.0) == 22.0               # tests/grid.rs:109
+    # the fast pipeline is the default (it falls back to the COMPAT kernels by itself); no switches set
+    assert cfg.mode == gpe._lib.MODE_NATIVE and cfg.flags == 0
+    assert ctypes.sizeof(gpe._lib.GpeConfig) == 64 and ctypes.sizeof(gpe._lib.GpePipelineInfo) == 48
 
 
 def test_no_gpu_means_loud_failure_not_fallback(gpe):

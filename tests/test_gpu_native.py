@@ -167,22 +167,34 @@ def test_native_out_of_box_scene_uses_compat_kernels(gpe, oracle):
         st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
     _assert_positions(st.positions(), sim.pos, "out-of-box start")
     st.ctx.sync()
+    info = st.ctx.pipeline_info()
+    assert (info["pipeline"], info["reason"]) == (gpe._lib.PIPELINE_COMPAT, gpe._lib.REASON_OUT_OF_BOX), info
     st.close(); sim.close()
 
 
 def test_native_overfull_windows_use_compat_kernels(gpe, oracle):
-    """More particles in a 24x24-cell window than the smallest LDS cell window stages (here ~11 per unit^2):
-    the configuration-time check sends the context to the compat kernels -- exact, no error."""
-    n = 12_000
-    world = (33.0, 33.0)
-    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=12)
-    st = _native(gpe, pos, rad, world)
-    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
-    for s in range(3):
-        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
-    _assert_positions(st.positions(), sim.pos, "over-dense scene")
-    st.ctx.sync()
-    st.close(); sim.close()
+    """More particles in a 24x24-cell window than a context may ENTER the native kernels with (24576: here ~42 per
+    unit^2): the configuration-time check sends the context to the compat kernels -- exact, no error, and
+    gpe_get_pipeline_info says which kernels ran and why.  The same scene at a third of the density stays native
+    (its windows go through the sub-tile and spill windows)."""
+    L = gpe._lib
+    for n, expect in ((30_000, (L.PIPELINE_COMPAT, L.REASON_DENSE_WINDOWS)), (12_000, (L.PIPELINE_NATIVE, L.REASON_NONE))):
+        world = (26.0, 26.0) if n == 30_000 else (33.0, 33.0)
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=12)
+        st = _native(gpe, pos, rad, world)
+        sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+        oracle.set_threads(8)
+        try:
+            for s in range(3):
+                st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        finally:
+            oracle.set_threads(1)
+        _assert_positions(st.positions(), sim.pos, "over-dense scene, n = %d" % n)
+        st.ctx.sync()
+        info = st.ctx.pipeline_info()                      # the host can see which kernels ran, and why
+        assert (info["pipeline"], info["reason"]) == expect, info
+        assert (info["compat_steps"], info["native_steps"]) == ((3, 0) if expect[0] == L.PIPELINE_COMPAT else (0, 3)), info
+        st.close(); sim.close()
 
 
 def test_native_add_particles(gpe, oracle):
@@ -202,14 +214,13 @@ def test_native_add_particles(gpe, oracle):
     st.close(); sim.close()
 
 
-def test_native_spill_arena_is_exact(gpe, oracle, monkeypatch):
-    """GPE_NATIVE_FORCE=1 keeps an over-dense scene on the native kernels: every 8x8 tile overflows the LDS
+def test_native_spill_arena_is_exact(gpe, oracle):
+    """GPE_FLAG_NATIVE_FORCE keeps an over-dense scene on the native kernels: every 8x8 tile overflows the LDS
     windows and is resolved with its particle arrays in the global spill arena -- same bits as the oracle."""
-    monkeypatch.setenv("GPE_NATIVE_FORCE", "1")
     n = 12_000
     world = (33.0, 33.0)
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=12)
-    st = _native(gpe, pos, rad, world)
+    st = _native(gpe, pos, rad, world, flags=gpe._lib.FLAG_NATIVE_FORCE)
     st.ctx.set_profiling(True)
     sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
     for s in range(3):
@@ -239,10 +250,9 @@ def test_native_mouse_blob_hands_over_without_error(gpe):
     a.close(); b.close()
 
 
-def test_native_crushed_cells_are_exact(gpe, oracle, monkeypatch):
+def test_native_crushed_cells_are_exact(gpe, oracle):
     """Cells of ~100 members (a crushed pile): whole-wave resolution (9..64 members) and its blocked form (65..256)
-    in the sub-tile and spill windows, kept on the native kernels by GPE_NATIVE_FORCE -- same bits as the oracle."""
-    monkeypatch.setenv("GPE_NATIVE_FORCE", "1")
+    in the sub-tile and spill windows, kept on the native kernels by GPE_FLAG_NATIVE_FORCE -- same bits as the oracle."""
     rng = np.random.default_rng(21)
     world = (40.0, 40.0)
     # a sparse background plus three blobs of 90, 150 and 240 particles inside one cell each
@@ -251,7 +261,7 @@ def test_native_crushed_cells_are_exact(gpe, oracle, monkeypatch):
              for c, k in (((11.1, 11.1), 90), ((22.1, 16.6), 150), ((30.9, 30.9), 240))]
     pos = np.concatenate([bg] + blobs).astype(np.float32)
     rad = np.full(len(pos), 0.5, np.float32)
-    st = _native(gpe, pos, rad, world)
+    st = _native(gpe, pos, rad, world, flags=gpe._lib.FLAG_NATIVE_FORCE)
     sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
     for s in range(3):
         st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
@@ -381,16 +391,14 @@ def _fuzz_scene(seed):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_native_fuzz_scenes_match_oracle(gpe, oracle, seed, monkeypatch):
+def test_native_fuzz_scenes_match_oracle(gpe, oracle, seed):
     """Seeded random scenes (ragged box sizes, thin worlds, boundary placements, clumps, several radii laws, gravity
     in any direction, three time steps, re-sorts at random steps, mouse on in a quarter of them): bit-exact
     positions, previous positions and particle ids after every step.  Even seeds pin the scene to the native
-    kernels (GPE_NATIVE_FORCE: clumps then go through the sub-tile and spill windows) and check that every step
+    kernels (GPE_FLAG_NATIVE_FORCE: clumps then go through the sub-tile and spill windows) and check that every step
     ran there; odd seeds leave the choice to the step policy."""
     pos, rad, world, max_r, gravity, dt, steps, resorts, mouse = _fuzz_scene(seed)
-    if seed % 2 == 0:
-        monkeypatch.setenv("GPE_NATIVE_FORCE", "1")
-    st = _native(gpe, pos, rad, world, gravity=gravity)
+    st = _native(gpe, pos, rad, world, gravity=gravity, flags=gpe._lib.FLAG_NATIVE_FORCE if seed % 2 == 0 else 0)
     st.ctx.set_profiling(True)
     p = oracle.default_params(world[0], world[1], max_r, gravity=gravity)
     if mouse is not None:
@@ -433,6 +441,13 @@ def test_native_sparse_huge_worlds(gpe, oracle, world, n):
     st.ctx.sync()
     ran_native = st.ctx.timings().get("native/collide+verlet", (0, 0))[1]
     assert ran_native == (5 if world[0] < 71000 else 0)
+    info = st.ctx.pipeline_info()
+    if world[0] < 71000:
+        assert (info["pipeline"], info["reason"]) == (gpe._lib.PIPELINE_NATIVE, gpe._lib.REASON_NONE), info
+        blocks = (int(world[0] / 1.1) // 8 + 1) * (int(world[1] / 1.1) // 8 + 1)
+        assert info["sort_passes"] == ((blocks - 1).bit_length() + 7) // 8 == 3
+    else:
+        assert (info["pipeline"], info["reason"]) == (gpe._lib.PIPELINE_COMPAT, gpe._lib.REASON_GRID_TOO_WIDE), info
     st.close(); sim.close()
 
 
@@ -483,3 +498,73 @@ def test_relaxed_cloud_long_run_native_equals_compat(gpe):
         assert np.array_equal(a.positions(), b.positions()), "after %d steps" % done
         assert np.array_equal(a.previous_positions(), b.previous_positions()), "after %d steps" % done
     a.close(); b.close()
+
+
+def test_kept_block_table_equals_sorting_every_step(gpe, oracle):
+    """The radix passes run only when a particle has left the reach of the block table they last produced
+    (k_native_hash / kDrift*).  Same bits as sorting every step (GPE_FLAG_SORT_EVERY_STEP) and as the oracle, with
+    gravity pulling the whole cloud across block boundaries, a Morton re-sort in the middle and particles added on the
+    way; and the passes did run on a fraction of the steps only."""
+    n = 120_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=33)
+    g = (0.0, -9.81)
+    a = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_NATIVE)
+    b = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_NATIVE, flags=gpe._lib.FLAG_SORT_EVERY_STEP)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5, gravity=g))
+    oracle.set_threads(8)
+    try:
+        for s in range(90):
+            rs = s in (0, 50)
+            a.update(1 / 60, resort=rs); b.update(1 / 60, resort=rs); sim.step(1 / 60, resort=rs)
+            if s % 10 == 9 or s in (0, 50, 51):
+                pa = a.positions()
+                assert np.array_equal(pa, b.positions()), "kept table vs sorting every step, step %d" % s
+                _assert_positions(pa, sim.pos, "kept table vs oracle, step %d" % s)
+    finally:
+        oracle.set_threads(1)
+    ia, ib = a.ctx.pipeline_info(), b.ctx.pipeline_info()
+    assert ia["pipeline"] == gpe._lib.PIPELINE_NATIVE and ia["reason"] == gpe._lib.REASON_NONE
+    assert ia["native_steps"] == 90 and ib["native_steps"] == 90
+    assert ib["native_sorts"] >= 90                     # (+ the configuration-time sort)
+    assert 2 <= ia["native_sorts"] <= 45, ia            # first step, re-sort step, and whenever the fall demands it
+    a.close(); b.close(); sim.close()
+
+
+def test_kept_block_table_survives_drift_in_every_direction(gpe, oracle):
+    """Particles leaving their sorted block to the left, right, up and down by different amounts per step (a cloud
+    with a velocity field set through the previous positions), gravity off: exact against the oracle at every step,
+    while sorts happen only now and then."""
+    n = 40_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=5)
+    rng = np.random.default_rng(6)
+    vel = (rng.random((n, 2), dtype=np.float32) - np.float32(0.5)) * np.float32(1.6)     # up to 0.8 units per step
+    prev = (pos - vel).astype(np.float32)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE, prev=prev)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5), prev=prev)
+    for s in range(40):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        _assert_positions(st.positions(), sim.pos, "drifting cloud, step %d" % s)
+    info = st.ctx.pipeline_info()
+    assert info["native_steps"] == 40 and 2 <= info["native_sorts"] < 40, info
+    st.close(); sim.close()
+
+
+def test_pipeline_info_reports_mode_table_and_default(gpe):
+    """gpe_get_pipeline_info: a context created with the defaults runs the NATIVE kernels (gpe_config_default); COMPAT
+    by request says so; a context without particles has nothing to run.  (GPE_REASON_TABLE_TOO_LARGE cannot be
+    reached while GPE_REASON_GRID_TOO_WIDE caps an axis at 65000 cells: 8125 x 8125 blocks < 2^27.)"""
+    L = gpe._lib
+    pos, rad = gpe.scenes.uniform_cloud(5000, (300.0, 200.0), seed=2)
+    st = gpe.State(pos, rad, world=(300.0, 200.0))                     # no mode given
+    i = st.ctx.pipeline_info()
+    assert (i["pipeline"], i["reason"]) == (L.PIPELINE_NATIVE, L.REASON_NONE) and i["sort_passes"] == 2, i
+    st.ctx.call("gpe_set_mode", L.MODE_COMPAT)
+    i = st.ctx.pipeline_info()
+    assert (i["pipeline"], i["reason"]) == (L.PIPELINE_COMPAT, L.REASON_MODE_COMPAT), i
+    st.close()
+    ctx = gpe.Context()
+    i = ctx.pipeline_info()
+    assert (i["pipeline"], i["reason"]) == (L.PIPELINE_COMPAT, L.REASON_NO_PARTICLES), i
+    ctx.close()

@@ -45,7 +45,7 @@ def _scene(gpe, kind, n, seed):
 def test_step_matches_oracle(gpe, oracle, kind, n, steps):
     world, pos, rad = _scene(gpe, kind, n, seed=1000 + n)
     max_r = float(np.abs(rad).max())
-    st = gpe.State(pos, rad, world=world)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
     sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], max_r))
     dt = 1.0 / 60.0
     for s in range(steps):
@@ -80,7 +80,7 @@ def test_gravity_and_mouse_match_oracle(gpe, oracle):
     n = 5000
     world, pos, rad = _scene(gpe, "reference_density", n, seed=77)
     g = (0.0, -9.81)
-    st = gpe.State(pos, rad, world=world, gravity=g)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT, gravity=g)
     p = oracle.default_params(world[0], world[1], 0.5, gravity=g)
     p.mouse_pressed, p.mouse_x, p.mouse_y = 1, world[0] * 0.4, world[1] * 0.6
     st.particles.mouse_click_callback(True, (p.mouse_x, p.mouse_y))
@@ -101,7 +101,7 @@ def test_negative_phantom_cells_and_unused_alias(gpe, oracle):
                     [0.0, 0.0], [0.05, 0.02], [30.0, 30.0]], np.float32)
     rad = np.full(len(pos), 0.5, np.float32)
     world = (64.0, 64.0)
-    st = gpe.State(pos, rad, world=world)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
     sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
     st.grid.build_cell_ids(); sim.grid_build()
     assert np.array_equal(st.grid.download_cell_ids(), sim.cell_ids)
@@ -120,8 +120,8 @@ def test_module_calls_compose_like_step(gpe, oracle):
     """gpe_grid_build / gpe_grid_sort / gpe_solve_collisions / gpe_integrate one by one == gpe_step."""
     n = 10_000
     world, pos, rad = _scene(gpe, "dense", n, seed=5)
-    a = gpe.State(pos, rad, world=world)
-    b = gpe.State(pos, rad, world=world)
+    a = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
+    b = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
     for s in range(4):
         a.update(0.01, resort=(s == 0))
         if s == 0:
@@ -139,7 +139,7 @@ def test_add_particles_matches_fresh_system(gpe, oracle):
     world = (200.0, 120.0)
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=21)
     extra_pos, extra_rad = gpe.scenes.mixed_radius_cloud(100, world, seed=22, radii=(1.0, 2.0, 3.0))
-    st = gpe.State(pos, rad, world=world)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
     st.update(1 / 60, resort=True)
     cur, prev = st.positions(), st.previous_positions()
     perm = st.particles.download_particle_ids()
@@ -159,8 +159,8 @@ def test_add_particles_matches_fresh_system(gpe, oracle):
 def test_run_equals_repeated_step(gpe):
     n = 20_000
     world, pos, rad = _scene(gpe, "reference_density", n, seed=9)
-    a = gpe.State(pos, rad, world=world)
-    b = gpe.State(pos, rad, world=world)
+    a = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
+    b = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
     a.run(1 / 60, 12, resort_every=5, resort_first=True)
     for s in range(12):
         b.update(1 / 60, resort=(s % 5 == 0))
@@ -173,7 +173,7 @@ def test_full_size_1m_properties(gpe, oracle):
     n = 1_000_000
     world = gpe.scenes.REF_WORLD
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
-    st = gpe.State(pos, rad, world=world)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
     sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
     st.update(1 / 60, resort=True); sim.step(1 / 60, resort=True)
     ids = st.particles.download_particle_ids()
