@@ -35,6 +35,68 @@ ALGO_BYTES_PER_PARTICLE = 148    # hash 12 + sort 68 + grid 8 + 
 RESORT_EVERY = 240               # 4 s at 60 Hz (particle_system.rs:13-14)
 PROFILE_EVERY = 10               # kernels of every 10th timed step are bracketed by HIP events (an event pair
                                  # per kernel on every step costs ~35% at 1M particles)
+MIN_TIMED_SECONDS = 0.5          # the K-step window is repeated until this much time has been measured (>= 1 window);
+MAX_WINDOWS = 400                # the MEDIAN window is reported: a 20-step window at 1M is 1.6 ms, too short alone
+
+
+class Schedule:
+    """The run's global step counter: a Morton re-sort on step 0 and on every RESORT_EVERY-th step of the RUN
+    (particle_system.rs:13-14, :45), wherever the timed windows happen to start."""
+
+    def __init__(self, run):
+        self.run, self.done = run, 0          # run(dt, steps, resort_every, resort_first)
+
+    def advance(self, dt, k):
+        while k > 0:
+            to_resort = (RESORT_EVERY - self.done % RESORT_EVERY) % RESORT_EVERY
+            if to_resort == 0:
+                self.run(dt, 1, 0, True)
+                self.done += 1; k -= 1
+                continue
+            c = min(k, to_resort)
+            self.run(dt, c, 0, False)
+            self.done += c; k -= c
+
+
+def timed_windows(sched, dt, steps, sync, dist, torch, min_seconds=MIN_TIMED_SECONDS, restore=None, max_steps=None):
+    """EXACTLY `steps` steps per window, each window bracketed by barrier + synchronize on both sides and reduced
+    with MAX over the ranks; windows are repeated until min_seconds have been measured.  Returns the list of window
+    times (seconds).  Every rank runs the same number of windows (the count follows from all-reduced times).
+    restore: called before every window -- puts the system back to the state the first window starts from, so that
+    every window times the SAME steps of the run (a cloud without damping relaxes: at 1M the step is 20 % slower after
+    4000 steps); without it the windows follow each other, at most max_steps steps in all."""
+    times = []
+    while True:
+        if restore is not None:
+            restore()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sched.advance(dt, steps)
+        sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        times.append(el)
+        if sum(times) >= min_seconds or len(times) >= MAX_WINDOWS:
+            return times
+        if max_steps is not None and (len(times) + 1) * steps > max_steps:
+            return times
+
+
+def window_stats(times, steps):
+    import statistics
+    med = statistics.median(times)
+    return {"windows": len(times), "steps_per_window": steps, "timed_steps_total": steps * len(times),
+            "timed_seconds_total": round(sum(times), 4), "median_window_ms": round(med * 1e3, 4),
+            "first_window_ms": round(times[0] * 1e3, 4), "min_window_ms": round(min(times) * 1e3, 4),
+            "max_window_ms": round(max(times) * 1e3, 4)}
 
 
 def log(*a):
@@ -94,8 +156,9 @@ def kernel_rooflines(timings, n_particles, mode):
     return out
 
 
-def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gravity, device):
-    """Returns (seconds for `steps` steps, max over ranks; timings dict of rank 0)."""
+def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gravity, device, min_seconds=MIN_TIMED_SECONDS):
+    """Returns (median seconds for `steps` steps over the timed windows, max over ranks; timings dict of rank 0; world;
+    window statistics; pipeline info)."""
     import numpy as np
     world = gpe.scenes.world_for(n)
     t0 = time.time()
@@ -106,32 +169,41 @@ def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gra
                    mode=gpe.MODE_NATIVE if mode == "native" else gpe.MODE_COMPAT)
     del pos, rad
     dt = 1.0 / 60.0
-    st.run(dt, warmup, resort_every=RESORT_EVERY, resort_first=True)      # first frame re-sorts
-    st.ctx.sync()
+    sched = Schedule(lambda d, k, every, first: st.run(d, k, resort_every=every, resort_first=first))
+    restore = None
+    if min_seconds > 0.0 and warmup >= 1:
+        # Repeated windows time the same steps [warmup, warmup + steps) of the run: the state after warmup - 1 steps is
+        # kept on the host, put back before every window (gpe_set_particles: ParticleSystem::new_from_buffers), and the
+        # last warm-up step runs again, untimed (like any first step on fresh buffers it sorts).
+        import ctypes
+        sched.advance(dt, warmup - 1)
+        st.ctx.sync()
+        snap = (np.ascontiguousarray(st.positions()), np.ascontiguousarray(st.previous_positions()),
+                np.ascontiguousarray(st.radii()), sched.done)
+        pv = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+        def restore():
+            st.ctx.call("gpe_set_particles", pv(snap[0]), pv(snap[1]), pv(snap[2]), len(snap[2]))
+            sched.done = snap[3]
+            sched.advance(dt, 1)
+            st.ctx.sync()
+    else:
+        sched.advance(dt, warmup)           # first frame re-sorts
+        st.ctx.sync()
     st.ctx.set_profiling(PROFILE_EVERY)     # HIP-event pairs around the kernels of every k-th step
     st.ctx.reset_timings()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st.run(dt, steps, resort_every=RESORT_EVERY, resort_first=False)
-    st.ctx.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    times = timed_windows(sched, dt, steps, st.ctx.sync, dist, torch, min_seconds, restore=restore)
+    import statistics
+    elapsed = statistics.median(times)
     timings = st.ctx.timings()
+    pipe = st.ctx.pipeline_info()
     p = st.positions()
     assert np.isfinite(p).all(), "non-finite positions after the run"
     st.close()
-    return elapsed, timings, world
+    return elapsed, timings, world, window_stats(times, steps), pipe
 
 
-def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gravity, device):
+def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gravity, device, min_seconds=MIN_TIMED_SECONDS):
     """N > 1: one shard per GPU (gpu-physics-engine_amd/sharded.py): block ownership, one-block ghost band and
     migration over RCCL point-to-point every step.  Weak scaling: every rank fills its own rectangle of the
     world with n_per_gpu particles at the reference density."""
@@ -157,22 +229,15 @@ def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gr
     del pos, rad, gid
     st = sharded.ShardedState(eng, dec, rank)
     dt = 1.0 / 60.0
-    st.run(dt, warmup, resort_every=RESORT_EVERY, resort_first=True)
+    sched = Schedule(lambda d, k, every, first: st.run(d, k, resort_every=every, resort_first=first))
+    sched.advance(dt, warmup)
     eng.sync()
     eng.ctx.set_profiling(PROFILE_EVERY)
     eng.ctx.reset_timings()
     st.stats = {"migrants": 0, "ghosts": 0, "steps": 0}
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st.run(dt, steps, resort_every=RESORT_EVERY, resort_first=False)
-    eng.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    times = timed_windows(sched, dt, steps, eng.sync, dist, torch, min_seconds, max_steps=max(steps, 240))
+    import statistics
+    elapsed = statistics.median(times)
     timings = eng.ctx.timings()
     _, p, _ = st.owned()
     info = {"owned": st.n_owned, "process_grid": [px, py],
@@ -186,6 +251,7 @@ def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gr
         info["ghosts_per_step"] = st.stats["ghosts"] / max(1, st.stats["steps"])
         info["migrants_per_step"] = st.stats["migrants"] / max(1, st.stats["steps"])
     assert np.isfinite(p).all(), "non-finite positions after the run"
+    info["windows"] = window_stats(times, steps)
     eng.close()
     return elapsed, timings, world, info
 
@@ -250,8 +316,29 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     alive = list(procs)
+
+    def stop_children(signum=None, frame=None):       # exact PIDs of our own children, nothing else
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except Exception:
+                q.kill()
+        if signum is not None:
+            raise SystemExit(128 + signum)
+
+    import signal
+    signal.signal(signal.SIGTERM, stop_children)
+    signal.signal(signal.SIGINT, stop_children)
+    deadline = time.time() + float(os.environ.get("GPE_BENCH_DEADLINE_S", "3000"))
     while alive:
         time.sleep(0.2)
+        if time.time() > deadline:
+            log("bench.py: the ranks did not finish within the deadline -- stopping them")
+            stop_children()
+            return 124
         for p in list(alive):
             code = p.poll()
             if code is None:
@@ -318,27 +405,87 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def extra_entry(name, run, n_per_gpu, ngpu, steps, mode, resort_note):
-    el, tim, world, info = run
+def load_traffic():
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath))
+    except Exception:
+        return {}
+
+
+def roofline_block(timings, n, mode, tj):
+    """The `roofline` object of one workload: the dominant kernel (largest total time among the kernels with an
+    algorithmic byte count) priced against HBM, with the two figures that say what actually binds it."""
+    roofs = kernel_rooflines(timings, n, mode)
+    if not roofs:
+        return None, roofs
+    name, d = max(roofs.items(), key=lambda kv: kv[1]["total_ms"])
+    traffic = tj.get(mode, {}).get(name, {}).get(str(n))
+    note = None
+    if traffic is not None:
+        measured_on = tj.get("_measured_on", {})
+        digest = kernel_source_digest()
+        if measured_on.get("csrc_sha16") != digest:
+            note = ("PMC figures were measured on csrc %s (%s); this build is %s -- re-run scripts/gpu_profile_r03.sh"
+                    % (measured_on.get("csrc_sha16"), measured_on.get("commit"), digest))
+            log("warning: " + note)
+    valu, issue_frac = None, None
+    sq = tj.get("sq", {}).get(name, {}).get(str(n))
+    if sq and sq.get("GRBM_GUI_ACTIVE"):
+        cycles = sq["GRBM_GUI_ACTIVE"] / 8.0                      # the counter is summed over the 8 XCDs
+        per_simd = sq["SQ_INSTS_VALU"] / 1024.0                   # 256 CUs x 4 SIMDs
+        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD is executing a VALU instruction: x 4 / (1024 SIMDs x
+        # kernel cycles) is the fraction of the kernel during which the VALU pipes are busy -- the roofline this kernel
+        # actually sits on (DESIGN.md 5); HBM `frac` is the contract's figure.
+        issue_frac = round(sq.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (1024.0 * cycles), 3)
+        # one SIMD issues a wave64 VALU instruction per ~2.2 cycles (fma / integer add) to ~4.1 cycles (compare +
+        # select), measured with 4-8 waves per SIMD: profiles/r02/valu_issue_probe.txt
+        valu = {"valu_wave_insts_per_launch": sq["SQ_INSTS_VALU"], "kernel_cycles": round(cycles),
+                "issue_busy_frac_at_2.2_cycles": round(per_simd * 2.2 / cycles, 3),
+                "issue_busy_frac_at_4.1_cycles": round(per_simd * 4.1 / cycles, 3),
+                "lanes_active_per_valu_inst": round(sq.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * max(1, sq.get("SQ_ACTIVE_INST_VALU", 1))), 3),
+                "wave_cycles_waiting_frac": round(sq.get("SQ_WAIT_ANY", 0) / max(1, sq.get("SQ_WAVE_CYCLES", 1)), 3),
+                "source": "SQ counters recorded in profiles/traffic.json (rocprofv3 --pmc; not measured by this run)"}
+    block = {"bound": "hbm", "kernel": name, "achieved": round(d["GBps"], 1), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": round(d["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+             "traffic_is": "HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/traffic.json "
+                           "(not measured by this run)" + ("; STALE: " + note if note else ""),
+             "bytes_per_launch": d["bytes"], "avg_launch_ms": round(d["avg_ms"], 5),
+             "launches": d["calls"], "launches_are": "the launches of every %dth timed step (hipEvent pairs on the "
+                                                     "library's stream)" % PROFILE_EVERY,
+             "issue_frac": issue_frac,
+             "issue_frac_is": "VALU-busy fraction of the kernel: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), "
+                              "from the same PMC record -- the limit this kernel is closest to (not HBM)",
+             "valu_issue": valu}
+    return block, roofs
+
+
+def log_timings(timings, roofs):
+    for name, (tot, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0]):
+        extra = "  %.0f GB/s algorithmic" % roofs[name]["GBps"] if name in roofs else ""
+        log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
+
+
+def extra_entry(name, run, n_per_gpu, ngpu, steps, mode, resort_note, tj):
+    el, tim, world, wstats, info = run
     sps = steps / el
-    roofs = kernel_rooflines(tim, n_per_gpu, mode)
-    for kname, (tot, calls) in sorted(tim.items(), key=lambda kv: -kv[1][0]):
-        extra = "  %.0f GB/s algorithmic" % roofs[kname]["GBps"] if kname in roofs else ""
-        log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (kname, tot, calls, tot / max(1, calls), extra))
-    dom = max(roofs.items(), key=lambda kv: kv[1]["total_ms"]) if roofs else None
+    roofline, roofs = roofline_block(tim, n_per_gpu, mode, tj)
+    log_timings(tim, roofs)
     return {
         "workload": name, "n_gpus": ngpu, "particles_per_gpu": n_per_gpu, "particles_total": n_per_gpu * ngpu,
-        "world": [world[0], world[1]], "steps": steps, "schedule": resort_note,
+        "world": [world[0], world[1]], "steps": steps, "schedule": resort_note, "windows": wstats,
         "system_steps_per_sec": round(sps, 3), "shard_steps_per_sec": round(sps * ngpu, 3),
         "ms_per_step": round(1e3 / sps, 4),
         "particle_steps_per_sec": round(sps * n_per_gpu * ngpu, 1),
         "step_algorithmic_GBps": round(ALGO_BYTES_PER_PARTICLE * n_per_gpu * ngpu * sps / 1e9, 1),
         "step_frac_of_hbm_roofline_per_gpu": round(ALGO_BYTES_PER_PARTICLE * n_per_gpu * sps / 1e9 / HBM_PEAK_GBS, 4),
-        "dominant_kernel": dom[0] if dom else None,
-        "dominant_kernel_avg_ms": round(dom[1]["avg_ms"], 4) if dom else None,
-        "dominant_kernel_GBps": round(dom[1]["GBps"], 1) if dom else None,
-        "dominant_kernel_frac": round(dom[1]["GBps"] / HBM_PEAK_GBS, 4) if dom else None,
-        "sharding": info,
+        "roofline": roofline,
+        "dominant_kernel": roofline["kernel"] if roofline else None,
+        "dominant_kernel_avg_ms": roofline["avg_launch_ms"] if roofline else None,
+        "dominant_kernel_GBps": roofline["achieved"] if roofline else None,
+        "dominant_kernel_frac": roofline["frac"] if roofline else None,
+        "pipeline": info if isinstance(info, dict) and "pipeline" in info else None,
+        "sharding": info if isinstance(info, dict) and "pipeline" not in info else None,
     }
 
 
@@ -425,40 +572,52 @@ def main():
     gpe._lib.load()
 
     n = args.particles
-    shard_info = None
+    tj = load_traffic()
+    # The CPU baseline first (rank 0, N = 1): the GPU legs then run back to back at the end of the process.
+    cpu = None
+    if ngpu == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle) ...")
+        cpu = cpu_baseline(gpe, min(n, 1_000_000))
+        cpu["value"] = round(cpu["value"], 4)
+    shard_info, pipe = None, None
     if world_size > 1:
         elapsed, timings, world, shard_info = run_sharded(gpe, torch, dist, rank, world_size, n, args.steps,
                                                           args.warmup, args.gravity, local_rank)
+        wstats = shard_info.pop("windows")
     else:
-        elapsed, timings, world = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
-                                               args.mode, args.gravity, local_rank)
+        elapsed, timings, world, wstats, pipe = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
+                                                             args.mode, args.gravity, local_rank)
     # The 100M legs, shaped like BASELINE.json configs[2..4]: gravity on, warm-up 10 steps (the first re-sorts),
-    # then the timed window with the re-sort every 240 steps INSIDE it.
+    # then timed windows with the re-sort every 240 steps of the run INSIDE them.
     extras = []
     if not args.no_extra and args.extra_particles != n:
         ne, xs = args.extra_particles, args.extra_steps
-        sched = "warm-up 10 steps (first one re-sorts), %d timed steps, re-sort every %d steps of the run" % (xs, RESORT_EVERY)
+        sched = ("warm-up 10 steps (first one re-sorts), windows of %d timed steps (median reported), re-sort every %d "
+                 "steps of the run" % (xs, RESORT_EVERY))
         if world_size > 1:
             per = max(1, ne // world_size)
             log("extra workload: %d particles in all over %d GPUs (%d per GPU), gravity on ..." % (per * world_size, world_size, per))
+            r = run_sharded(gpe, torch, dist, rank, world_size, per, xs, 10, "on", local_rank, min_seconds=0.0)
             extras.append(("%d particles over %d GPUs (%d per GPU), gravity on (0,-9.81)%s" %
                            (per * world_size, world_size, per, " = BASELINE.json configs[3]" if world_size == 4 else ""),
-                           run_sharded(gpe, torch, dist, rank, world_size, per, xs, 10, "on", local_rank), per, sched))
+                           (r[0], r[1], r[2], r[3].pop("windows"), r[3]), per, sched, xs))
             log("extra workload: %d particles per GPU (%d in all), gravity on ..." % (ne, ne * world_size))
+            r = run_sharded(gpe, torch, dist, rank, world_size, ne, xs, 10, "on", local_rank, min_seconds=0.0)
             extras.append(("%d particles per GPU, %d in all, gravity on (0,-9.81)%s" %
                            (ne, ne * world_size, " = BASELINE.json configs[4]" if world_size == 8 else ""),
-                           run_sharded(gpe, torch, dist, rank, world_size, ne, xs, 10, "on", local_rank), ne, sched))
+                           (r[0], r[1], r[2], r[3].pop("windows"), r[3]), ne, sched, xs))
         else:
             log("extra workload: %d particles, gravity on ..." % ne)
             extras.append(("%d particles, gravity on (0,-9.81) = BASELINE.json configs[2]" % ne,
-                           run_workload(gpe, torch, None, 0, 1, ne, xs, 10, args.mode, "on", local_rank) + (None,), ne, sched))
+                           run_workload(gpe, torch, None, 0, 1, ne, xs, 10, args.mode, "on", local_rank, min_seconds=0.0),
+                           ne, sched, xs))
             if args.long_steps > 0:
                 log("extra workload: the headline workload over %d steps ..." % args.long_steps)
-                extras.append(("%d particles, gravity %s, %d timed steps: the headline workload over a long window "
-                               "(the cloud relaxes into touching clusters, later steps resolve more pairs)"
+                extras.append(("%d particles, gravity %s, ONE window of %d timed steps: the headline workload over a long "
+                               "run (the cloud relaxes into touching clusters, later steps resolve more pairs)"
                                % (n, args.gravity, args.long_steps),
                                run_workload(gpe, torch, None, 0, 1, n, args.long_steps, args.warmup, args.mode,
-                                            args.gravity, local_rank) + (None,), n,
+                                            args.gravity, local_rank, min_seconds=0.0), n,
                                "warm-up %d steps (first one re-sorts), %d timed steps, re-sort every %d steps of the run"
                                % (args.warmup, args.long_steps, RESORT_EVERY), args.long_steps))
     soak = None
@@ -473,52 +632,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     steps_per_s = args.steps / elapsed
     mode = "native" if world_size > 1 else args.mode
-    roofs = kernel_rooflines(timings, n, mode)
-    for name, (tot, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0]):
-        extra = ""
-        if name in roofs:
-            extra = "  %.0f GB/s algorithmic" % roofs[name]["GBps"]
-        log("  %-44s %9.3f ms total  %6d calls  %8.4f ms/call%s" % (name, tot, calls, tot / max(1, calls), extra))
-    dom = max(roofs.items(), key=lambda kv: kv[1]["total_ms"]) if roofs else None
-    traffic, traffic_note, tj = None, None, {}
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if dom and os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(mode, {}).get(dom[0], {}).get(str(n))
-            measured_on = tj.get("_measured_on", {})
-            digest = kernel_source_digest()
-            if traffic is not None and measured_on.get("csrc_sha16") != digest:
-                traffic_note = ("PMC traffic was measured on csrc %s (%s); this build is %s -- re-run scripts/gpu_profile.sh"
-                                % (measured_on.get("csrc_sha16"), measured_on.get("commit"), digest))
-                log("warning: " + traffic_note)
-        except Exception:
-            traffic = None
-    valu = None
-    try:
-        sq = tj.get("sq", {}).get(dom[0], {}).get(str(n)) if dom else None
-        if sq and sq.get("GRBM_GUI_ACTIVE"):
-            cycles = sq["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
-            per_simd = sq["SQ_INSTS_VALU"] / 1024.0                   # 256 CUs x 4 SIMDs
-            # one SIMD issues a wave64 VALU instruction per ~2.2 cycles (fma / integer add) to ~4.1 cycles (compare +
-            # select), measured with 4-8 waves per SIMD: profiles/r02/valu_issue_probe.txt
-            valu = {"valu_wave_insts_per_launch": sq["SQ_INSTS_VALU"], "kernel_cycles": round(cycles),
-                    "issue_busy_frac_at_2.2_cycles": round(per_simd * 2.2 / cycles, 3),
-                    "issue_busy_frac_at_4.1_cycles": round(per_simd * 4.1 / cycles, 3),
-                    "lanes_active_per_valu_inst": round(sq.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * max(1, sq.get("SQ_ACTIVE_INST_VALU", 1))), 3),
-                    "wave_cycles_waiting_frac": round(sq.get("SQ_WAIT_ANY", 0) / max(1, sq.get("SQ_WAVE_CYCLES", 1)), 3),
-                    "source": "SQ counters recorded in profiles/traffic.json (rocprofv3 --pmc; not measured by this run)"}
-    except Exception:
-        valu = None
-    roofline = None
-    if dom:
-        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(dom[1]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_is": "HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/traffic.json "
-                                  "(not measured by this run)" + ("; STALE: " + traffic_note if traffic_note else ""),
-                    "bytes_per_launch": dom[1]["bytes"], "avg_launch_ms": round(dom[1]["avg_ms"], 5),
-                    "launches": dom[1]["calls"], "launches_are": "the launches of every %dth timed step" % PROFILE_EVERY,
-                    "valu_issue": valu}
+    roofline, roofs = roofline_block(timings, n, mode, tj)
+    log_timings(timings, roofs)
 
     # Whole-job value: every GPU advances one shard of `particles_per_gpu` particles per step, so the job
     # completes n_gpus shard-steps per step (== plain steps/s at n_gpus = 1).
@@ -527,6 +642,12 @@ def main():
         "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u32",
         "data": "synthetic",
+        "timed_steps_total": wstats["timed_steps_total"],
+        "timing": dict(wstats, value_is="the MEDIAN window of `steps` steps; windows (each bracketed by barrier + "
+                                        "synchronize, max over ranks) repeat until %.1f s have been measured; at n_gpus = 1 "
+                                        "every window starts from the same state (the one after `warmup` steps), at "
+                                        "n_gpus > 1 the windows follow each other, at most 240 steps in all"
+                                        % MIN_TIMED_SECONDS),
         "config": {"workload": "%d particles per GPU, gravity %s, world %.1f x %.1f, radius 0.5, uniform random "
                                "(BASELINE.json configs[1] at 1M per GPU)" % (n, args.gravity, world[0], world[1]),
                    "particles_per_gpu": n, "particles_total": n * ngpu, "mode": mode, "resort_every": RESORT_EVERY,
@@ -540,16 +661,14 @@ def main():
                    "launched_by": "bench.py itself (child ranks spawned before any GPU call)"
                                   if os.environ.get("GPE_BENCH_SELF_LAUNCHED") == "1" else
                                   ("torch.distributed.run / external launcher" if world_size > 1 else "single process"),
+                   "pipeline": pipe,
                    "sharding": shard_info},
         "roofline": roofline,
     }
-    if ngpu == 1 and not args.no_cpu_baseline:
-        log("cpu baseline (oracle, 1 thread) ...")
-        result["cpu_baseline"] = cpu_baseline(gpe, min(n, 1_000_000))
-        result["cpu_baseline"]["value"] = round(result["cpu_baseline"]["value"], 4)
+    if cpu is not None:
+        result["cpu_baseline"] = cpu
     if extras:
-        result["extra_workloads"] = [extra_entry(e[0], e[1], e[2], ngpu, e[4] if len(e) > 4 else args.extra_steps, mode, e[3])
-                                     for e in extras]
+        result["extra_workloads"] = [extra_entry(e[0], e[1], e[2], ngpu, e[4], mode, e[3], tj) for e in extras]
     if soak is not None:
         result["soak"] = soak
     print(json.dumps(result), flush=True)

@@ -93,6 +93,7 @@ constexpr int kCtlError = 8;                   // sticky
 constexpr int kCtlNeedSort = 10;               // [parity] the hash found a particle outside the drift its code can express
 constexpr int kCtlFresh = 12;                  // [parity] the radix passes ran: the block table describes THIS step's positions
 constexpr int kCtlSorts = kNativeCtlSorts;     // steps whose radix passes ran (running count, gpe_get_pipeline_info)
+constexpr int kCtlStragglers0 = 9, kCtlStragglers1 = 15;   // [parity] stragglers found by the step's hash so far
 // How far a particle may have left the 8x8-cell block it was sorted into (cells beyond the block's extent, per
 // direction) and still be found by every tile that needs it.  A tile looks up the blocks of tile +- 8 cells but keeps
 // only the window [x0-5, x1+4] x [y0-3, y1+2] (kCone* + 1): a kept particle that moved right by dr cells comes from a
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                                                             uint64_t div_magic, uint32_t *__restrict__ exc_count,
                                                             uint2 *__restrict__ exc_entry,
                                                             uint32_t *__restrict__ exc_count_next, int32_t exc_tiles_x,
-                                                            int32_t exc_tiles_y)
+                                                            int32_t exc_tiles_y, uint32_t straggler_limit)
 {
     // sorted_key[i] = the block key particle i had when the radix passes last ran (they keep it up to date,
     // k_onesweep.hip): the sorted ids and the block table still describe THAT grouping.  As long as every particle
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
         if (threadIdx.x == 0) {                                        // the next step's words; this step's if it must sort
             tile_ctl[kCtlNeedSort + (parity ^ 1u)] = 0;
             tile_ctl[kCtlFresh + (parity ^ 1u)] = 0;
+            tile_ctl[parity ? kCtlStragglers0 : kCtlStragglers1] = 0;
             if (!sorted_key) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
         }
     }
@@ -305,6 +307,16 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 // (A straggler's relative cell is still right mod 8, which is what the tiles use when the passes run.)
                 codes[idx[u]] = ((uint32_t)(relx + kDriftLeft) & 15u) | (((uint32_t)(rely + kDriftDown) & 15u) << 4) |
                                 (neighbour_overlap_mask(p[u], rad[u], cx, cy, cell_size) << 8) | (straggler ? kCodeStraggler : 0u);
+                // Stragglers are meant to be the few fast particles of a hot cloud.  When the whole cloud moves (free
+                // fall) a large share of the particles runs out of reach within a step or two: handing millions of
+                // them over, at up to four atomics each, costs more than the sort that makes them ordinary again.
+                const uint64_t ms = __ballot(straggler);
+                if (ms != 0) {                                           // (wave-uniform)
+                    uint32_t before = 0;
+                    if (lane_id() == (int)__builtin_ctzll(ms))
+                        before = atomicAdd(&tile_ctl[parity ? kCtlStragglers1 : kCtlStragglers0], (uint32_t)__popcll(ms));
+                    if (before + (uint32_t)__popcll(ms) > straggler_limit) drifted = true;    // (the adding lane only: enough)
+                }
                 if (straggler) {
                     // every 32x32 tile whose window [32 tx - 5, 32 tx + 35] x [32 ty - 3, 32 ty + 33] holds the cell
                     // (sub-tiles of the over-capacity launch read their parent's list: their windows lie inside its)
@@ -1744,7 +1756,8 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
                            (uint4 *)N.block_table, gated ? 0ull : pairs,    // gated: the first radix pass resets the table
                            N.host_stat, reuse ? N.sorted_key : nullptr, parity, div_magic,
                            N.exc_count + (size_t)parity * N.exc_tiles, N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots,
-                           N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles, N.exc_tiles_x, N.exc_tiles_y);
+                           N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles, N.exc_tiles_x, N.exc_tiles_y,
+                           (uint32_t)std::max<uint64_t>(64, n >> 11));      // more stragglers than 0.05 % of the particles: sort
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
@@ -1782,6 +1795,7 @@ gpe_status native_configure(gpe_ctx *c)
     N.dense_hold = false;
     N.steps_since_check = 0;
     N.sort_state_valid = false;          // particles, box or keys changed: the kept grouping is of something else
+    N.quiet_steps = 0;
     N.always_sort = (c->cfg.flags & GPE_FLAG_SORT_EVERY_STEP) != 0;
     N.reason = GPE_REASON_NO_PARTICLES;
     if (c->n == 0 || !(c->cell_size > 0.0f)) return GPE_OK;
@@ -2095,11 +2109,20 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // tiles whose window exceeded the LDS capacity: 16x16 tiles, 8x8 tiles, spill arena.  (Measured and dropped:
         // running this launch on a second stream beside the dense one -- the stream fork/join costs ~8 us per step,
         // more than the normally empty launch it hides; it only pays in clustered scenes.)
+        // The launch takes its work items from a ticket counter, so ANY grid is correct; an empty launch of 1024
+        // workgroups (8 waves and 36 KB of LDS each) costs ~6 us, 8 % of the 1 M step.  While the tiles have reported no
+        // over-capacity tile for a while (the statistic lags by the steps in flight) the grid is 128 workgroups; the
+        // first reported tile brings the full grid back.  A surprise only makes that one step's launch slower.
         Scope s(c, "native/collide-dense-regions");
+        if (N.host_stat && N.host_stat[kStatOverflow] != 0) N.quiet_steps = 0;
+        else if (N.quiet_steps < 0xFFFFFFFFu) ++N.quiet_steps;
+        // (Only where the empty launch matters: from a few million particles on its 6 us are noise, and a surprise -- the
+        // statistic lags by up to 64 steps -- would cost those steps milliseconds each.)
+        const uint32_t ogrid = (N.quiet_steps > 96 && c->n <= (4ull << 20)) ? 128u : 1024u;
         if (A.order_keys)
-            hipLaunchKernelGGL(k_collide_overflow<true>, dim3(1024), dim3(kNatThreads), 0, c->stream, A);
+            hipLaunchKernelGGL(k_collide_overflow<true>, dim3(ogrid), dim3(kNatThreads), 0, c->stream, A);
         else
-            hipLaunchKernelGGL(k_collide_overflow<false>, dim3(1024), dim3(kNatThreads), 0, c->stream, A);
+            hipLaunchKernelGGL(k_collide_overflow<false>, dim3(ogrid), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
     }
     return GPE_OK;

@@ -238,19 +238,28 @@ def test_native_context_allocates_grid_buffers_on_demand(gpe, oracle):
     """A NATIVE context whose steps run on the native kernels does not hold the reference's 4N grid /
     collision-cell arrays and 4N sort partners (84 B per particle); the first per-module call that needs them
     allocates them, and the module calls then give the reference's results."""
-    import torch
+    import ctypes
+
+    def free_bytes():
+        # hipMemGetInfo of the runtime libgpe.so itself links (torch carries a second copy of the HIP runtime, which
+        # refuses to initialise when this one already owns the device)
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
     n = 4_000_000
     world = gpe.scenes.world_for(n)
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=77)
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    warm = gpe.Context(); warm.close()                 # the runtime is up before the first reading
+    free0 = free_bytes()
     st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
     st.run(1 / 60, 3, resort_every=0, resort_first=True)
     st.ctx.sync()
-    lean = free0 - torch.cuda.mem_get_info()[0]
+    lean = free0 - free_bytes()
     st.grid.update()                                   # Grid::update -> the 4N arrays and the 4N sort partners
     st.ctx.sync()
-    full = free0 - torch.cuda.mem_get_info()[0]
+    full = free0 - free_bytes()
     assert full - lean >= 72 * n, (lean, full)         # 52 B of 4N arrays + the sort partners growing from N to 4N
     assert lean <= 200 * n + (96 << 20), (lean, full)  # SoA x 2, index arrays, native sort buffers, spill arena
     # and the arrays hold what the oracle's grid holds for the same positions
