@@ -165,8 +165,22 @@ class GpuBuffer:
 class ParticleSystem:
     """particles/particle_system.rs:16-24."""
 
+    SORT_INTERVAL = 4.0      # seconds (particle_system.rs:13-14)
+
     def __init__(self, ctx):
+        import time
         self.ctx = ctx
+        self._mouse = (False, (0.0, 0.0))
+        self._clock = time.monotonic
+        self.last_sort_time = self._clock() - self.SORT_INTERVAL     # :45,97: the first frame sorts
+
+    def is_it_time_to_sort(self):
+        """particle_system.rs:229-231 (wall clock, like the reference)."""
+        return self._clock() - self.last_sort_time >= self.SORT_INTERVAL
+
+    def reset_last_sort_time(self):
+        """particle_system.rs:233-235."""
+        self.last_sort_time = self._clock()
 
     @classmethod
     def new_from_buffers(cls, ctx, positions, radii, prev=None):
@@ -209,7 +223,14 @@ class ParticleSystem:
         self.ctx.call("gpe_integrate", float(dt))
 
     def mouse_click_callback(self, pressed, position):
+        """particle_system.rs:221-224 -> particle_integration.rs:176-181."""
+        self._mouse = (bool(pressed), (float(position[0]), float(position[1])))
         self.ctx.call("gpe_set_mouse", 1 if pressed else 0, float(position[0]), float(position[1]))
+
+    def mouse_move_callback(self, position):
+        """particle_system.rs:225-227 -> particle_integration.rs:182-185: the position moves, the button state stays."""
+        self._mouse = (self._mouse[0], (float(position[0]), float(position[1])))
+        self.ctx.call("gpe_set_mouse", 1 if self._mouse[0] else 0, float(position[0]), float(position[1]))
 
     def download_home_cell_ids(self):
         return self.ctx.download(L.HOME_CELL_IDS, np.uint32)
@@ -349,6 +370,15 @@ class State:
     def update(self, dt, resort=False):
         """state.rs:115-131 (dt is explicit instead of wall clock, the re-sort an explicit flag)."""
         self.ctx.call("gpe_step", float(dt), L.STEP_RESORT if resort else 0)
+
+    def update_wallclock(self, dt):
+        """state.rs:115-131 with the reference's own re-sort policy: every SORT_INTERVAL seconds of wall clock
+        (particle_system.rs:229-235), first frame included."""
+        resort = self.particles.is_it_time_to_sort()
+        self.update(dt, resort=resort)
+        if resort:
+            self.particles.reset_last_sort_time()
+        return resort
 
     def run(self, dt, steps, resort_every=0, resort_first=True):
         self.ctx.call("gpe_run", float(dt), int(steps), int(resort_every), 1 if resort_first else 0)

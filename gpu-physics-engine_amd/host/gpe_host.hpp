@@ -15,6 +15,7 @@
 //   State                      -> gpe::State            state.rs:21-31 (update() == gpe_step)
 #pragma once
 
+#include <chrono>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -136,7 +137,18 @@ class ParticleSystem {
     float get_max_radius() const { float r = 0; ctx_->call(gpe_max_radius(ctx_->raw(), &r)); return r; } // :291
     void sort_by_cell_id(float /*cell_size: the Grid's, state.rs:123*/) { ctx_->call(gpe_morton_resort(ctx_->raw())); }
     void update_positions(float dt) { ctx_->call(gpe_integrate(ctx_->raw(), dt)); }                      // :245
-    void mouse_click_callback(bool pressed, Vec2 p) { ctx_->call(gpe_set_mouse(ctx_->raw(), pressed, p.x, p.y)); }
+    void mouse_click_callback(bool pressed, Vec2 p)                                                      // :221-224
+    {
+        mouse_pressed_ = pressed;
+        ctx_->call(gpe_set_mouse(ctx_->raw(), pressed, p.x, p.y));
+    }
+    void mouse_move_callback(Vec2 p) { ctx_->call(gpe_set_mouse(ctx_->raw(), mouse_pressed_, p.x, p.y)); } // :225-227
+    // the reference's wall-clock re-sort policy (SORT_INTERVAL = 4 s, :13-14; the first frame sorts, :45,97)
+    bool is_it_time_to_sort() const                                                                      // :229-231
+    {
+        return !sorted_once_ || std::chrono::steady_clock::now() - last_sort_time_ >= std::chrono::seconds(4);
+    }
+    void reset_last_sort_time() { last_sort_time_ = std::chrono::steady_clock::now(); sorted_once_ = true; } // :233-235
     std::vector<uint32_t> download_home_cell_ids() const { return ctx_->download<uint32_t>(GPE_HOME_CELL_IDS); }
     std::vector<uint32_t> download_particle_ids() const { return ctx_->download<uint32_t>(GPE_PARTICLE_IDS); }
     ParticleBuffers download_particle_buffers() const                                                    // :258-265
@@ -152,6 +164,9 @@ class ParticleSystem {
    private:
     explicit ParticleSystem(const Context &ctx) : ctx_(&ctx) {}
     const Context *ctx_;
+    bool mouse_pressed_ = false;
+    bool sorted_once_ = false;
+    std::chrono::steady_clock::time_point last_sort_time_{};
 };
 
 class Grid {
@@ -241,6 +256,21 @@ class State {
         : ctx_(world, mode), particles_(ParticleSystem::new_from_buffers(ctx_, positions, radii)), grid_(ctx_, particles_),
           collision_system_(ctx_, 2, particles_, grid_) {}
     void update(float dt, bool resort) { ctx_.call(gpe_step(ctx_.raw(), dt, resort ? GPE_STEP_RESORT : 0u)); }   // state.rs:115-131
+    // ... with the reference's own wall-clock re-sort policy (state.rs:122-125, particle_system.rs:229-235)
+    bool update(float dt)
+    {
+        const bool resort = particles_.is_it_time_to_sort();
+        update(dt, resort);
+        if (resort) particles_.reset_last_sort_time();
+        return resort;
+    }
+    gpe_pipeline_info pipeline_info() const
+    {
+        gpe_pipeline_info info{};
+        info.struct_size = sizeof(info);
+        ctx_.call(gpe_get_pipeline_info(ctx_.raw(), &info));
+        return info;
+    }
     ParticleSystem &particles() { return particles_; }
     Grid &grid() { return grid_; }
     CollisionSystem &collision_system() { return collision_system_; }

@@ -436,9 +436,26 @@ class ShardedState:
                     raise RuntimeError("rank 0 could not create an RCCL id: %s" % (L.load().gpe_last_error(None) or b"").decode())
                 raw = (C.c_uint8 * L.COMM_ID_BYTES)(*ident.tolist())
                 torch.cuda.synchronize(e.device)
-                e.ctx.call("gpe_shard_comm_init", raw, self.rank, self.ws)          # collective
-                self.transport = "rccl"
-                return
+                # The choice of transport must be the SAME on every rank (a rank that left for the torch exchange while
+                # its peers sit in ncclRecv would hang the job at the first step): every rank reports how its own
+                # communicator set-up went, and the minimum decides.  (Both ends of a neighbour pair size their segments
+                # from the same all-reduced numbers, _plan_device_exchange, so the send / recv counts match by construction.)
+                ok, why = 1, None
+                try:
+                    e.ctx.call("gpe_shard_comm_init", raw, self.rank, self.ws)      # collective
+                    e.sync()
+                except Exception as exc:                               # noqa: BLE001 -- any backend error
+                    ok, why = 0, exc
+                flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                if int(flag.item()) == 1:
+                    self.transport = "rccl"
+                    return
+                try:
+                    e.ctx.call("gpe_shard_comm_destroy")
+                except Exception:                                      # noqa: BLE001
+                    pass
+                raise RuntimeError("a rank could not set the communicator up" + (": %s" % why if why else " (not this one)"))
             except Exception as exc:                                   # noqa: BLE001 -- any backend error
                 print("[gpe sharded] in-library RCCL transport unavailable (%s: %s); moving the segments with "
                       "torch.distributed" % (type(exc).__name__, exc), file=sys.stderr, flush=True)
