@@ -714,6 +714,17 @@ __device__ __forceinline__ bool pair_response(const bool active, float &p1x, flo
     return __ballot(hit) != 0;
 }
 
+// The test pair_response starts with, on its own: can this pair collide at these positions?  (hit implies cand.)
+__device__ __forceinline__ bool pair_candidate(const float ax, const float ay, const float ar, const float bx,
+                                               const float by, const float br)
+{
+    const float vx = ax - bx, vy = ay - by;
+    const float q = vx * vx + vy * vy;
+    const float radius_sum = ar + br;
+    const float rs2 = radius_sum * radius_sum;
+    return q <= rs2 * 1.000001f && q >= 9.9e-9f;
+}
+
 // The reference's pair resolution (collision_solver.wgsl:66-118), on LDS-resident positions: one lane walks the
 // pairs (a, b), a < b, of its cell.  Bit-exact restatements that shorten the dependent chain:
 //  * the next partner's position is fetched while the current pair is computed: within one `a` loop every pair
@@ -754,6 +765,7 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
 #ifndef GPE_VAR_SMALLCELLS
 #define GPE_VAR_SMALLCELLS 1
 #endif
+
 template <class L>
 __device__ __forceinline__ void resolve_small_cells(L &S, const bool on, const uint32_t b, const uint32_t n,
                                                     const float stiffness)
@@ -827,6 +839,7 @@ template <class L>
 __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint32_t n, const int a,
                                               const float stiffness)
 {
+    const int group_base = lane_id() & ~((int)kGroupLanes - 1);
     // order the members: rank = members with a smaller object index (they are distinct)
     const bool has = (uint32_t)a < n;
     const uint32_t my_slot = has ? (uint32_t)S.mem[b + a] : 0u;
@@ -835,7 +848,6 @@ __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint
 #pragma unroll
     for (int i = 0; i < (int)kGroupLanes; ++i) rank += ((uint32_t)__shfl((int)my_id, i, kGroupLanes) < my_id) ? 1u : 0u;
     // forward permute: lane r receives the slot of the member of rank r
-    const int group_base = lane_id() & ~((int)kGroupLanes - 1);
     const uint32_t a_slot = (uint32_t)__builtin_amdgcn_ds_permute((group_base + (int)(has ? rank : (uint32_t)a)) << 2,
                                                                   (int)my_slot);
     // step-start state of the lane's particle; also what lane 0 is fed with (nothing touches particle b before
@@ -1633,6 +1645,432 @@ __device__ __forceinline__ void resolve_quarter(OverflowLds<ORD> &u, const Colli
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The 32x32 tile of the dense launch, second form: DIRECT cell slots.
+//
+// process_tile builds the member lists of a window by a counting sort -- count the memberships per cell (P1), scan the
+// counts (P2), fill the lists (P3): three barrier-separated phases whose LDS round trips every wave of the tile waits
+// for, and the tile is bound by exactly that, the latency of its chain of phases (profiles/r03/
+// ab_p5_candidate_cull_rejected.txt).  At the densities the dense launch is for, cells are small (25 % packing: 0.2 % of
+// the cells hold more than six members), so here every cell of the tile's zone owns six member slots outright: the
+// atomic that counts a membership hands out the slot, and P2 / P3 are gone.  The colour passes read a cell's members
+// with one LDS access instead of list -> cell offsets -> members.  A seventh member goes to a short side list; cells of
+// 7..64 members are gathered from it by the wave that resolves them.  A window with more than kBigCap such entries (a
+// compressed scene) is left to process_tile's windows in the over-capacity launch, as is anything else this form has
+// no room for.  Same operations per particle pair in the same order: same bits.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kDirectSlots = 6;                // member slots a zone cell owns
+constexpr int kBigCap = 96;                    // memberships beyond that, per tile
+template <int T, int CAP, bool LID>
+struct TileDirect {
+    static constexpr int TILE = T;
+    static constexpr bool kGlobal = false;
+    static constexpr bool kLid = LID;
+    static constexpr int kSlots = CAP;
+    static constexpr int HXL = kConeLeft + 1, HXR = kConeRight + 1, HYL = kConeDown + 1, HYR = kConeUp + 1;
+    static constexpr int RWX = T + HXL + HXR, RWY = T + HYL + HYR;   // cell window: where a kept particle's home may lie
+    // zone cells: the 2 x 2 colour groups from the even cell (x0 - 4, y0 - 2) on, (T + 8) x (T + 4) cells; the colour
+    // zones (kCone*) lie inside.  Only memberships of zone cells are filed.
+    static constexpr int ZX = T + 8, ZY = T + 4, NZ = ZX * ZY, QZ = NZ / 4;
+    static constexpr int ZOX = HXL - kConeLeft, ZOY = HYL - kConeDown;   // window coordinate of zone cell (0, 0)
+    static constexpr int NB = (T + 2 * kHalo) / 8;
+    static constexpr int NBLK = NB * NB;
+    static constexpr int QMAX = GPE_QMAX_MAIN;
+    static constexpr int RAWCAP = QMAX * kNatThreads;
+    static constexpr int WC = 16;
+    uint32_t lid[LID ? CAP : 1];
+    float px[CAP], py[CAP], rad[CAP];
+    uint32_t id[CAP];
+    uint8_t own[CAP];          // the particle's home cell lies in the tile
+    uint32_t cntw[(NZ + 1) / 2];   // members per zone cell, two 16-bit counters per word (LDS atomics are 32 bit)
+    __device__ __forceinline__ uint32_t cnt_inc(int i)                // returns the value before the add
+    {
+        const uint32_t sh = (uint32_t)(i & 1) * 16u;
+        return (atomicAdd(&cntw[i >> 1], 1u << sh) >> sh) & 0xFFFFu;
+    }
+    __device__ __forceinline__ uint32_t cnt_get(int i) const { return (cntw[i >> 1] >> ((uint32_t)(i & 1) * 16u)) & 0xFFFFu; }
+    // members: kDirectSlots per zone cell, then 64 per wave for the cells gathered from the side list.  (Named like
+    // TileLds' member array: the resolvers index S.mem[b + k].)
+    uint16_t mem[kDirectSlots * NZ + kNatWaves * 64];
+    union {
+        uint16_t list[4 * QZ]; // active cells, one segment per colour (P4 on)
+        uint8_t sblk[RAWCAP];  // P0-P1 only: region block a looked-up slot came from
+        static_assert(RAWCAP <= 8 * QZ, "sblk fits under list");
+    };
+    uint16_t wlist[4 * WC];    // cells of more than kDirectSlots members, per colour
+    uint32_t big[kBigCap];     // memberships that found their cell's slots taken: zone cell << 16 | particle slot
+    uint32_t lcnt[12];
+    uint32_t bstart[NBLK];
+    uint32_t bcnt[NBLK];
+    uint32_t boff[NBLK + 1];
+    uint32_t s_w[16];
+    uint32_t misc[6];          // [0] looked up, [2] hand the tile on, [3] kept, [4] side-list entries
+};
+
+template <bool ORD, class L>
+__device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, const int tx, const int ty)
+{
+    constexpr int T = L::TILE;
+    constexpr int RWX = L::RWX, RWY = L::RWY, NB = L::NB, NBLK = L::NBLK, QMAX = L::QMAX;
+    constexpr int ZX = L::ZX, ZY = L::ZY, NZ = L::NZ, QZ = L::QZ;
+    constexpr int HX = L::HXL, HY = L::HYL;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int ox = tx * T - HX, oy = ty * T - HY;                      // origin of the cell window
+    const int box = (tx * T - kHalo) >> 3, boy = (ty * T - kHalo) >> 3;   // first looked-up block
+    GPE_STAMP_BEGIN();
+
+    // ---- P0: clear the counters, look the region's blocks up, slot -> block map (as process_tile) ------------------
+    for (int i = tid; i < (NZ + 1) / 2; i += kNatThreads) S.cntw[i] = 0;
+    if (tid < 12) S.lcnt[tid] = 0;
+    if (tid < NBLK) {
+        const int bi = tid % NB, bj = tid / NB;
+        const int lbx = box + bi - A.bx0, lby = boy + bj - A.by0;
+        uint32_t start = 0, count = 0;
+        if (lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
+            const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
+            if (mb < A.entries) {
+                const uint2 se = A.table[mb];                        // empty blocks hold (0xFFFFFFFF, 0)
+                if (se.y > se.x) { start = se.x; count = se.y - se.x; }
+            }
+        }
+        S.bstart[tid] = start;
+        S.bcnt[tid] = count;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t carry = 0;
+        for (int base = 0; base < NBLK; base += 64) {
+            const int b = base + lane;
+            const uint32_t cb = (b < NBLK) ? S.bcnt[b] : 0u;
+            const uint32_t inc = wave_inclusive_scan(cb);
+            if (b < NBLK) S.boff[b] = carry + inc - cb;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        if (lane == 0) { S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[2] = 0; S.misc[3] = 0; S.misc[4] = 0; }
+    } else if (tid < 64 + (NB - 2) * (NB - 2)) {
+        const int wi = (tid - 64) % (NB - 2), wj = (tid - 64) / (NB - 2);
+        uint32_t w = 0;
+#pragma unroll
+        for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+            for (int di = 0; di < 3; ++di) w += S.bcnt[(wj + dj) * NB + wi + di];
+        if (w > kWindowReport) atomicMax(&A.tile_ctl[kCtlWindowMax], w);
+    }
+    __syncthreads();
+    const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);
+    if (P == 0) return true;
+    const bool stale = __builtin_amdgcn_readfirstlane((int)*A.fresh) == 0;
+    const int rel_mask = stale ? -1 : 7;
+    const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
+    uint32_t n_exc = 0;
+    if (stale && A.exc_count) {
+        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
+        n_exc = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.exc_count[pt]), kExcSlots);
+    }
+    if (P > (uint32_t)L::RAWCAP) return false;                         // more looked-up particles than slots
+    {
+        constexpr int SHARE = (kNatThreads / NBLK) > 0 ? (kNatThreads / NBLK) : 1;
+        for (int b = tid % NBLK, sub = tid / NBLK; sub < SHARE && b < NBLK; b += kNatThreads) {
+            const uint32_t lo = S.boff[b], hi = S.boff[b + 1];
+            for (uint32_t i = lo + sub; i < hi; i += SHARE) S.sblk[i] = (uint8_t)b;
+        }
+    }
+    __syncthreads();
+    GPE_STAMP(0);
+
+    // ---- P1: gather, keep, and file every membership straight into its cell's slots ---------------------------------
+    // one membership: the counter's old value is the slot; the seventh member of a cell goes to the side list
+    auto file = [&](const int zx, const int zy, const uint32_t s) {
+        if ((unsigned)zx < (unsigned)ZX && (unsigned)zy < (unsigned)ZY) {
+            const int zc = zy * ZX + zx;
+            const uint32_t k = S.cnt_inc(zc);
+            if (k < (uint32_t)kDirectSlots) S.mem[zc * kDirectSlots + (int)k] = (uint16_t)s;
+            else {
+                const uint32_t e = atomicAdd(&S.misc[4], 1u);
+                if (e < (uint32_t)kBigCap) S.big[e] = ((uint32_t)zc << 16) | s;
+            }
+        }
+    };
+    auto insert = [&](const uint32_t s, const float2 pp, const float pr, const uint32_t pid, const uint32_t lidv,
+                      const int lx, const int ly, uint32_t over) {
+        S.px[s] = pp.x; S.py[s] = pp.y; S.rad[s] = pr; S.id[s] = pid;
+        if constexpr (L::kLid) S.lid[s] = lidv;
+        S.own[s] = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? 1 : 0;
+        const int zx = lx - L::ZOX, zy = ly - L::ZOY;
+        file(zx, zy, s);
+        // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three); neighbour
+        // k of the scan (y outer, x inner, centre skipped): dx = {-1,0,1,-1,1,-1,0,1}[k], dy = {-1,-1,-1,0,0,1,1,1}[k]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (over == 0) break;
+            const int k = __ffs((int)over) - 1;
+            over &= over - 1u;
+            const int kk = k + (k >= 4 ? 1 : 0);                       // position in the 3 x 3 scan with the centre
+            file(zx + kk % 3 - 1, zy + kk / 3 - 1, s);
+        }
+    };
+    constexpr int QP = QMAX >= 2 ? 2 : 1;
+    for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QP * kNatThreads) {
+        uint32_t pid[QP], blk[QP], cc[QP];
+        float2 pp[QP];
+        float pr[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {                                 // branch-free, all loads in flight: see process_tile
+            const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * kNatThreads, P - 1u);
+            blk[q] = S.sblk[s];
+            pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
+        }
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            pp[q] = A.pos_in[pid[q]];
+            pr[q] = A.radius[pid[q]];
+            cc[q] = A.codes[pid[q]];
+        }
+        uint32_t lidq[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) lidq[q] = pid[q];
+        if constexpr (ORD) {
+#pragma unroll
+            for (int q = 0; q < QP; ++q) pid[q] = A.order_keys[pid[q]];
+        }
+        int lxq[QP], lyq[QP];
+        bool keep[QP];
+        uint32_t slot[QP];
+        uint64_t mq[QP];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
+            lxq[q] = (int)(blk[q] % NB) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
+            lyq[q] = (int)(blk[q] / NB) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
+            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
+            mq[q] = __ballot(keep[q]);
+            cnt += (uint32_t)__popcll(mq[q]);
+        }
+        uint32_t base = 0;
+        if (lane == 0 && cnt) base = atomicAdd(&S.misc[3], cnt);       // kept particles get consecutive slots
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            slot[q] = base + popc_below_lane(mq[q]);
+            base += (uint32_t)__popcll(mq[q]);
+            keep[q] = keep[q] && slot[q] < (uint32_t)L::kSlots;          // over capacity: handed on below
+        }
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+            if (keep[q]) insert(slot[q], pp[q], pr[q], pid[q], lidq[q], lxq[q], lyq[q], (cc[q] >> 8) & 0xFFu);
+    }
+    if (n_exc != 0 && tid < 64) {                                      // stragglers handed to the tile (see process_tile)
+        const bool have = (uint32_t)tid < n_exc;
+        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
+        const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + (have ? (uint32_t)tid : 0u)];
+        uint32_t pid = en.x;
+        const float2 pp = A.pos_in[pid];
+        const float pr = A.radius[pid];
+        const uint32_t cc = A.codes[pid];
+        const uint32_t lidq = pid;
+        if constexpr (ORD) pid = A.order_keys[pid];
+        const int lx = (int)(en.y & 0xFFFFu) - ox, ly = (int)(en.y >> 16) - oy;
+        bool keep = have && lx >= 0 && lx < RWX && ly >= 0 && ly < RWY;
+        const uint64_t mk = __ballot(keep);
+        uint32_t base = 0;
+        if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t sl = base + popc_below_lane(mk);
+        keep = keep && sl < (uint32_t)L::kSlots;
+        if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, (cc >> 8) & 0xFFu);
+    }
+    __syncthreads();
+    GPE_STAMP(1);
+    const uint32_t PS = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[3]);
+    if (PS > (uint32_t)L::kSlots) return false;                        // more kept particles than the window stages
+    if (PS == 0) return true;
+    const uint32_t n_big = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[4]);
+    if (n_big > (uint32_t)kBigCap) return false;                       // crowded cells: process_tile's windows take it
+
+    // the tile's own particles and their previous positions: fetched here, used in P6 (as process_tile)
+    const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
+    constexpr int QOWN = (L::kSlots + kNatThreads - 1) / kNatThreads;
+    uint32_t own_id[QOWN];
+    float2 own_prev[QOWN];
+    {
+        uint32_t fetch[QOWN];
+#pragma unroll
+        for (int q = 0; q < QOWN; ++q) {
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            own_id[q] = 0xFFFFFFFFu;
+            fetch[q] = 0u;
+            if (q >= 1 && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar)
+            const uint32_t sc = min(s, PS - 1u);
+            const bool own = s < PS && S.own[sc] != 0;
+            uint32_t id = S.id[sc];
+            asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
+            if constexpr (ORD) id = S.lid[sc];
+            own_id[q] = own ? id : 0xFFFFFFFFu;
+            fetch[q] = (own && id < n_owned) ? id : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < QOWN; ++q) {
+            own_prev[q] = make_float2(0.f, 0.f);
+            if (q >= 1 && PS <= (uint32_t)q * kNatThreads) continue;
+            if (A.fuse_verlet) own_prev[q] = A.prev[fetch[q]];
+        }
+    }
+
+    // ---- P4: active cells per colour (the walk of process_tile over the 2 x 2 colour groups; a cell's member count is
+    //          its counter).  List entry: zone cell | class data << 12: cells of 2-3 members (one lane each; bit 12: three)
+    //          from the front, cells of 4-6 (a lane group; members - 4) from the back; cells of 7-64 in the wave list.
+    {
+        constexpr int ZW = ZX / 2, ZH = ZY / 2, QC = ZW * ZH;
+        static_assert(QC == QZ && NZ < 4096, "list entries: 12 bits of cell");
+        for (int base = 0; base < QC; base += kNatThreads) {
+            const int i = base + tid;
+            const int gx2 = 2 * (i % ZW), gy2 = 2 * (i / ZW);          // zone coordinates of the group's first cell
+            int zc[4];
+            uint32_t cnt[4];
+            static_assert(ZX % 2 == 0, "the two cells of a group's row share a counter word");
+            {
+                const int z0 = gy2 * ZX + gx2;                         // even
+                const uint32_t w0 = (i < QC) ? S.cntw[z0 >> 1] : 0u, w1 = (i < QC) ? S.cntw[(z0 + ZX) >> 1] : 0u;
+                zc[0] = z0; zc[1] = z0 + 1; zc[2] = z0 + ZX; zc[3] = z0 + ZX + 1;
+                cnt[0] = w0 & 0xFFFFu; cnt[1] = w0 >> 16; cnt[2] = w1 & 0xFFFFu; cnt[3] = w1 >> 16;
+            }
+            uint64_t ms[4], mg[4];
+            bool single[4], group[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int lx = gx2 + (c & 1) + L::ZOX, ly = gy2 + (c >> 1) + L::ZOY;   // window coordinates
+                const int gxx = ox + lx, gyy = oy + ly;
+                const int exl = HX - lx, exr = lx - (HX + T - 1), eyl = HY - ly, eyr = ly - (HY + T - 1);
+                const bool in_zone = exl <= kConeLeft - c && exr <= kConeRight - c && eyl <= kConeDown - (c >> 1) &&
+                                     eyr <= kConeUp - (c >> 1);
+                const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
+                const bool act = (cnt[c] >= 2) && !unused_alias && in_zone;
+                group[c] = act && cnt[c] >= kGroupMin && cnt[c] <= (uint32_t)kDirectSlots;
+                bool wavec = act && cnt[c] > (uint32_t)kDirectSlots;
+                if (wavec) {
+                    if (cnt[c] > 64u) S.misc[2] = 1u;                  // a pile: the sub-tile windows resolve those
+                    const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
+                    if (k < (uint32_t)L::WC) S.wlist[c * L::WC + k] = (uint16_t)zc[c]; else S.misc[2] = 1u;
+                }
+                single[c] = act && !group[c] && !wavec;
+                mg[c] = __ballot(group[c]);
+                ms[c] = __ballot(single[c]);
+            }
+            uint32_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mine = (lane == c) ? (uint32_t)__popcll(ms[c]) : mine;
+                mine = (lane == 4 + c) ? (uint32_t)__popcll(mg[c]) : mine;
+            }
+            uint32_t mybase = 0;
+            if (lane < 8 && mine) mybase = atomicAdd(&S.lcnt[lane], mine);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)mybase, c);
+                const uint32_t bg = (uint32_t)__builtin_amdgcn_readlane((int)mybase, 4 + c);
+                if (single[c]) S.list[c * QZ + bs + popc_below_lane(ms[c])] = (uint16_t)(zc[c] | ((cnt[c] == 3u) ? 0x1000 : 0));
+                if (group[c]) S.list[c * QZ + (QZ - 1) - (bg + popc_below_lane(mg[c]))] = (uint16_t)(zc[c] | ((cnt[c] - kGroupMin) << 12));
+            }
+        }
+    }
+    __syncthreads();
+    GPE_STAMP(4);
+    if (S.misc[2]) return false;
+
+    // ---- P5: the four colour passes (collision_solver.rs:224) ----------------------------------------------------
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ns = S.lcnt[k], group_lanes = S.lcnt[4 + k] * kGroupLanes;
+        const uint32_t nw = min(S.lcnt[8 + k], (uint32_t)L::WC);
+        const uint32_t single_base = (group_lanes + 63u) & ~63u;      // waves are all-group or all-single
+        const uint32_t work = single_base + ns;
+        for (uint32_t i0 = 0; i0 < work; i0 += kNatThreads) {
+            const uint32_t i = i0 + (uint32_t)tid;
+            if (i < group_lanes) {
+                const uint32_t en = S.list[k * QZ + (QZ - 1) - (i / kGroupLanes)];
+                resolve_group(S, (en & 0xFFFu) * kDirectSlots, (en >> 12) + kGroupMin, (int)(i % kGroupLanes), A.stiffness);
+            } else if (i >= single_base && (i & ~63u) < work) {         // (whole waves: the walk uses ballots)
+                const bool on = i < work;
+                uint32_t b = 0, n = 0;
+                if (on) {
+                    const uint32_t en = S.list[k * QZ + (i - single_base)];
+                    b = (en & 0xFFFu) * kDirectSlots; n = 2u + (en >> 12);
+                }
+                resolve_small_cells(S, on, b, n, A.stiffness);
+            }
+        }
+        for (uint32_t i = (uint32_t)(kNatWaves - 1 - (tid >> 6)); i < nw; i += kNatWaves) {     // wave-uniform
+            // a cell of 7..64 members: its first six from its own slots, the others from the side list, into the wave's
+            // scratch run of the member array; then the whole-wave walk
+            const uint32_t zc = S.wlist[k * L::WC + i];
+            const uint32_t n = S.cnt_get((int)zc);
+            const uint32_t wb = (uint32_t)(kDirectSlots * NZ) + (uint32_t)(tid >> 6) * 64u;
+            if (lane < kDirectSlots) S.mem[wb + lane] = S.mem[zc * kDirectSlots + lane];
+            uint32_t filled = kDirectSlots;
+            for (uint32_t e0 = 0; e0 < n_big; e0 += 64u) {
+                const uint32_t e = e0 + (uint32_t)lane;
+                const uint32_t v = e < n_big ? S.big[e] : 0xFFFFFFFFu;
+                const bool hit = e < n_big && (v >> 16) == zc;
+                const uint64_t mh = __ballot(hit);
+                if (hit) S.mem[wb + filled + popc_below_lane(mh)] = (uint16_t)(v & 0xFFFFu);
+                filled += (uint32_t)__popcll(mh);
+            }
+            wave_lds_order();
+            resolve_wave(S, wb, n, A.stiffness);                       // (filled == n: every membership is in one of the two)
+            wave_lds_order();
+        }
+        __syncthreads();
+        GPE_STAMP(9 + k);
+    }
+
+    // ---- P6: write the tile's own particles back, K12 applied (as process_tile) ---------------------------------------
+#pragma unroll
+    for (int q = 0; q < QOWN; ++q) {
+        const uint32_t id = own_id[q];
+        if (id == 0xFFFFFFFFu) continue;
+        const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+        const float2 c = make_float2(S.px[s], S.py[s]);
+        if (A.fuse_verlet && id < n_owned) {
+            float2 o;
+            verlet_one(c.x, c.y, own_prev[q].x, own_prev[q].y, S.rad[s], A.vp, o.x, o.y);
+            A.prev[id] = c;
+            A.pos_out[id] = o;
+        } else {
+            A.pos_out[id] = c;
+        }
+    }
+    __syncthreads();
+    GPE_STAMP(6);
+    return true;
+}
+
+#ifndef GPE_CAP_DIRECT
+#define GPE_CAP_DIRECT 928
+#endif
+#ifndef GPE_CAP_DIRECT_ORD
+#define GPE_CAP_DIRECT_ORD 752
+#endif
+template <int T, int CAP, bool ORD>
+__global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide_direct(CollideArgs A)
+{
+    __shared__ TileDirect<T, CAP, ORD> S;
+    const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
+    const uint32_t per_xcd = (total + 7u) / 8u;
+    const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
+    const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
+    if (!process_tile_direct<ORD>(S, A, tx, ty)) {
+        if (threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
+            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+            else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
+        }
+    }
+}
+
 // Level 0: one workgroup per 32x32 tile, tiles dealt so that each XCD (blockIdx % 8) works through a
 // contiguous run of tile rows (neighbouring tiles share halo particles in that XCD's L2).
 template <int T, int CAP, bool ORD>
@@ -2099,10 +2537,18 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
         const uint32_t grid = ((total + 7u) / 8u) * 8u;
-        if (A.order_keys)
-            hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
-        else
-            hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0;
+        if (legacy) {
+            if (A.order_keys)
+                hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+            else
+                hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        } else {
+            if (A.order_keys)
+                hipLaunchKernelGGL((k_collide_direct<kTileMain, GPE_CAP_DIRECT_ORD, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+            else
+                hipLaunchKernelGGL((k_collide_direct<kTileMain, GPE_CAP_DIRECT, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        }
         GPE_HIP(c, hipGetLastError());
     }
     {
