@@ -117,6 +117,8 @@ def parse():
     ap.add_argument("--gravity", choices=["off", "on"], default="off")
     ap.add_argument("--no-extra", action="store_true", help="skip the 100M-particle extra workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-window", action="store_true",
+                    help="time ONE window of --steps steps (profiler runs: scripts/gpu_profile_r03.sh)")
     ap.add_argument("--extra-particles", type=int, default=100_000_000)
     ap.add_argument("--extra-steps", type=int, default=250,
                     help="timed steps of the 100M legs (the re-sort at step 240 falls inside the window)")
@@ -586,7 +588,8 @@ def main():
         wstats = shard_info.pop("windows")
     else:
         elapsed, timings, world, wstats, pipe = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
-                                                             args.mode, args.gravity, local_rank)
+                                                             args.mode, args.gravity, local_rank,
+                                                             min_seconds=0.0 if args.single_window else MIN_TIMED_SECONDS)
     # The 100M legs, shaped like BASELINE.json configs[2..4]: gravity on, warm-up 10 steps (the first re-sorts),
     # then timed windows with the re-sort every 240 steps of the run INSIDE them.
     extras = []

@@ -98,6 +98,32 @@ def test_native_equals_compat_100m(gpe):
     assert (p[:, 1] >= 0.5).all() and (p[:, 1] <= np.float32(world[1]) - 0.5).all()
 
 
+def test_config2_100m_gravity_on_matches_oracle_directly(gpe, oracle):
+    """BASELINE.json configs[2] itself -- 100 M particles, gravity on, 30480 x 10480 -- NATIVE against the ORACLE (not
+    against the compat kernels): 2 steps, the first one re-sorting, the oracle on the box's CPU share (same bits for any
+    thread count, tests/test_oracle_golden.py).  Positions, previous positions and the re-sort permutation, bit for bit."""
+    n = 100_000_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    g = (0.0, -9.81)
+    st = _native(gpe, pos, rad, world, gravity=g)
+    oracle.set_threads(_threads())
+    try:
+        sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5, gravity=g))
+        del pos, rad
+        for s in range(2):
+            st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        assert np.array_equal(st.positions(), sim.pos), "positions (100 M, gravity on, 2 steps)"
+        assert np.array_equal(st.previous_positions(), sim.prev), "previous positions (100 M, gravity on, 2 steps)"
+        assert np.array_equal(st.particles.download_particle_ids(), sim.particle_ids)
+        info = st.ctx.pipeline_info()
+        assert info["pipeline"] == gpe._lib.PIPELINE_NATIVE and info["native_steps"] == 2 and info["sort_passes"] == 3, info
+        st.ctx.sync()
+        st.close(); sim.close()
+    finally:
+        oracle.set_threads(1)
+
+
 def test_native_gravity_mouse_match_oracle(gpe, oracle):
     n = 8000
     world = gpe.scenes.world_for(n)

@@ -88,6 +88,62 @@ def test_two_ranks_one_gpu_equal_single_context(gpe, tmp_path, ws, n, world, gra
     assert np.array_equal(np.concatenate(prevs)[order], want_prev)
 
 
+def _config3_worker(rank, ws, port, n, steps, resort_at, out_dir):
+    """One rank of BASELINE.json configs[3]'s workload (100 M particles over 4 ranks, gravity on), all ranks on cuda:0."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        world = gpe.scenes.world_for(n)
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+        dec = sharded.Decomposition(world, np.float32(0.5) * np.float32(2.2), ws)
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        p_mine, r_mine = np.ascontiguousarray(pos[mine]), np.ascontiguousarray(rad[mine])
+        del pos, rad
+        eng = sharded.GpeEngine(p_mine, r_mine, mine, world, gravity=(0.0, -9.81), device=0)
+        st = sharded.ShardedState(eng, dec, rank, device_exchange=True)
+        for s in range(steps):
+            st.update(1 / 60, resort=(s in resort_at))
+        gid, p, q = st.owned()
+        eng.ctx.sync()
+        np.save(os.path.join(out_dir, "gid%d.npy" % rank), gid.astype(np.int64))
+        np.save(os.path.join(out_dir, "pos%d.npy" % rank), p)
+        np.save(os.path.join(out_dir, "prev%d.npy" % rank), q)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_workload_100m_over_four_ranks_on_one_gpu(gpe, tmp_path):
+    """BASELINE.json configs[3]'s WORKLOAD -- 100 M particles, gravity on, cut into 4 rectangles of 25 M -- with the four
+    ranks sharing cuda:0 over gloo (no multi-GPU box is available to the build, so this measures nothing about xGMI; it
+    does exercise the decomposition, the segment capacities, the order keys and the global re-sort indices at full
+    size): 3 steps, re-sorts at steps 0 and 2, bit-identical to the single-context NATIVE run."""
+    n, ws, steps, resort_at = 100_000_000, 4, 3, (0, 2)
+    port = _free_port()
+    mp.spawn(_config3_worker, args=(ws, port, n, steps, resort_at, str(tmp_path)), nprocs=ws, join=True)
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
+    ref = gpe.State(pos, rad, world=world, gravity=(0.0, -9.81), mode=gpe.MODE_NATIVE)
+    del pos, rad
+    for s in range(steps):
+        ref.update(1 / 60, resort=(s in resort_at))
+    want_pos, want_prev = ref.positions(), ref.previous_positions()
+    ref.close()
+    seen = np.zeros(n, bool)
+    for r in range(ws):
+        gid = np.load(os.path.join(str(tmp_path), "gid%d.npy" % r))
+        assert not seen[gid].any()
+        seen[gid] = True
+        # the global ids are the particles' indices in the unsharded system AFTER its re-sorts
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "pos%d.npy" % r)), want_pos[gid]), "rank %d positions" % r
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "prev%d.npy" % r)), want_prev[gid]), "rank %d previous positions" % r
+    assert seen.all()
+
+
 def _overflow_worker(rank, ws, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
