@@ -766,6 +766,7 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
 #define GPE_VAR_SMALLCELLS 1
 #endif
 
+
 template <class L>
 __device__ __forceinline__ void resolve_small_cells(L &S, const bool on, const uint32_t b, const uint32_t n,
                                                     const float stiffness)
