@@ -1662,22 +1662,22 @@ __device__ __forceinline__ void resolve_quarter(OverflowLds<ORD> &u, const Colli
 // ---------------------------------------------------------------------------------------------------
 constexpr int kDirectSlots = 6;                // member slots a zone cell owns
 constexpr int kBigCap = 96;                    // memberships beyond that, per tile
-template <int T, int CAP, bool LID>
+template <int TX_, int TY_, int CAP, bool LID, int NT_>
 struct TileDirect {
-    static constexpr int TILE = T;
+    static constexpr int TX = TX_, TY = TY_, NT = NT_, NW = NT_ / 64;   // tile (cells), threads, waves
     static constexpr bool kGlobal = false;
     static constexpr bool kLid = LID;
     static constexpr int kSlots = CAP;
     static constexpr int HXL = kConeLeft + 1, HXR = kConeRight + 1, HYL = kConeDown + 1, HYR = kConeUp + 1;
-    static constexpr int RWX = T + HXL + HXR, RWY = T + HYL + HYR;   // cell window: where a kept particle's home may lie
+    static constexpr int RWX = TX + HXL + HXR, RWY = TY + HYL + HYR;   // cell window: where a kept particle's home may lie
     // zone cells: the 2 x 2 colour groups from the even cell (x0 - 4, y0 - 2) on, (T + 8) x (T + 4) cells; the colour
     // zones (kCone*) lie inside.  Only memberships of zone cells are filed.
-    static constexpr int ZX = T + 8, ZY = T + 4, NZ = ZX * ZY, QZ = NZ / 4;
+    static constexpr int ZX = TX + 8, ZY = TY + 4, NZ = ZX * ZY, QZ = NZ / 4;
     static constexpr int ZOX = HXL - kConeLeft, ZOY = HYL - kConeDown;   // window coordinate of zone cell (0, 0)
-    static constexpr int NB = (T + 2 * kHalo) / 8;
-    static constexpr int NBLK = NB * NB;
+    static constexpr int NBX = (TX + 2 * kHalo) / 8, NBY = (TY + 2 * kHalo) / 8;
+    static constexpr int NBLK = NBX * NBY;
     static constexpr int QMAX = GPE_QMAX_MAIN;
-    static constexpr int RAWCAP = QMAX * kNatThreads;
+    static constexpr int RAWCAP = QMAX * NT;
     static constexpr int WC = 16;
     uint32_t lid[LID ? CAP : 1];
     float px[CAP], py[CAP], rad[CAP];
@@ -1692,7 +1692,7 @@ struct TileDirect {
     __device__ __forceinline__ uint32_t cnt_get(int i) const { return (cntw[i >> 1] >> ((uint32_t)(i & 1) * 16u)) & 0xFFFFu; }
     // members: kDirectSlots per zone cell, then 64 per wave for the cells gathered from the side list.  (Named like
     // TileLds' member array: the resolvers index S.mem[b + k].)
-    uint16_t mem[kDirectSlots * NZ + kNatWaves * 64];
+    uint16_t mem[kDirectSlots * NZ + NW * 64];
     union {
         uint16_t list[4 * QZ]; // active cells, one segment per colour (P4 on)
         uint8_t sblk[RAWCAP];  // P0-P1 only: region block a looked-up slot came from
@@ -1711,21 +1711,21 @@ struct TileDirect {
 template <bool ORD, class L>
 __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, const int tx, const int ty)
 {
-    constexpr int T = L::TILE;
-    constexpr int RWX = L::RWX, RWY = L::RWY, NB = L::NB, NBLK = L::NBLK, QMAX = L::QMAX;
+    constexpr int TX = L::TX, TY = L::TY, NT = L::NT, NW = L::NW;
+    constexpr int RWX = L::RWX, RWY = L::RWY, NBX = L::NBX, NBY = L::NBY, NBLK = L::NBLK, QMAX = L::QMAX;
     constexpr int ZX = L::ZX, ZY = L::ZY, NZ = L::NZ, QZ = L::QZ;
     constexpr int HX = L::HXL, HY = L::HYL;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int ox = tx * T - HX, oy = ty * T - HY;                      // origin of the cell window
-    const int box = (tx * T - kHalo) >> 3, boy = (ty * T - kHalo) >> 3;   // first looked-up block
+    const int ox = tx * TX - HX, oy = ty * TY - HY;                    // origin of the cell window
+    const int box = (tx * TX - kHalo) >> 3, boy = (ty * TY - kHalo) >> 3;   // first looked-up block
     GPE_STAMP_BEGIN();
 
     // ---- P0: clear the counters, look the region's blocks up, slot -> block map (as process_tile) ------------------
-    for (int i = tid; i < (NZ + 1) / 2; i += kNatThreads) S.cntw[i] = 0;
+    for (int i = tid; i < (NZ + 1) / 2; i += NT) S.cntw[i] = 0;
     if (tid < 12) S.lcnt[tid] = 0;
     if (tid < NBLK) {
-        const int bi = tid % NB, bj = tid / NB;
+        const int bi = tid % NBX, bj = tid / NBX;
         const int lbx = box + bi - A.bx0, lby = boy + bj - A.by0;
         uint32_t start = 0, count = 0;
         if (lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
@@ -1749,13 +1749,13 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (lane == 0) { S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[2] = 0; S.misc[3] = 0; S.misc[4] = 0; }
-    } else if (tid < 64 + (NB - 2) * (NB - 2)) {
-        const int wi = (tid - 64) % (NB - 2), wj = (tid - 64) / (NB - 2);
+    } else if (tid < 64 + (NBX - 2) * (NBY - 2)) {
+        const int wi = (tid - 64) % (NBX - 2), wj = (tid - 64) / (NBX - 2);
         uint32_t w = 0;
 #pragma unroll
         for (int dj = 0; dj < 3; ++dj)
 #pragma unroll
-            for (int di = 0; di < 3; ++di) w += S.bcnt[(wj + dj) * NB + wi + di];
+            for (int di = 0; di < 3; ++di) w += S.bcnt[(wj + dj) * NBX + wi + di];
         if (w > kWindowReport) atomicMax(&A.tile_ctl[kCtlWindowMax], w);
     }
     __syncthreads();
@@ -1764,15 +1764,21 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     const bool stale = __builtin_amdgcn_readfirstlane((int)*A.fresh) == 0;
     const int rel_mask = stale ? -1 : 7;
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
-    uint32_t n_exc = 0;
-    if (stale && A.exc_count) {
-        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
-        n_exc = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.exc_count[pt]), kExcSlots);
+    // stragglers: the lists of the 32x32 tiles this tile covers (one, or two side by side for a 64-cell-wide tile)
+    constexpr int NPAR = TX / 32;
+    static_assert(TY == 32 && (TX == 32 || TX == 64), "straggler lists are kept per 32x32 tile");
+    uint32_t n_exc[NPAR];
+#pragma unroll
+    for (int pi = 0; pi < NPAR; ++pi) {
+        n_exc[pi] = 0;
+        const int ptx = tx * NPAR + pi;
+        if (stale && A.exc_count && ptx < A.exc_tiles_x)
+            n_exc[pi] = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.exc_count[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)ptx]), kExcSlots);
     }
     if (P > (uint32_t)L::RAWCAP) return false;                         // more looked-up particles than slots
     {
-        constexpr int SHARE = (kNatThreads / NBLK) > 0 ? (kNatThreads / NBLK) : 1;
-        for (int b = tid % NBLK, sub = tid / NBLK; sub < SHARE && b < NBLK; b += kNatThreads) {
+        constexpr int SHARE = (NT / NBLK) > 0 ? (NT / NBLK) : 1;
+        for (int b = tid % NBLK, sub = tid / NBLK; sub < SHARE && b < NBLK; b += NT) {
             const uint32_t lo = S.boff[b], hi = S.boff[b + 1];
             for (uint32_t i = lo + sub; i < hi; i += SHARE) S.sblk[i] = (uint8_t)b;
         }
@@ -1797,7 +1803,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                       const int lx, const int ly, uint32_t over) {
         S.px[s] = pp.x; S.py[s] = pp.y; S.rad[s] = pr; S.id[s] = pid;
         if constexpr (L::kLid) S.lid[s] = lidv;
-        S.own[s] = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? 1 : 0;
+        S.own[s] = (lx >= HX && lx < HX + TX && ly >= HY && ly < HY + TY) ? 1 : 0;
         const int zx = lx - L::ZOX, zy = ly - L::ZOY;
         file(zx, zy, s);
         // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three); neighbour
@@ -1812,13 +1818,13 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         }
     };
     constexpr int QP = QMAX >= 2 ? 2 : 1;
-    for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QP * kNatThreads) {
+    for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QP * NT) {
         uint32_t pid[QP], blk[QP], cc[QP];
         float2 pp[QP];
         float pr[QP];
 #pragma unroll
         for (int q = 0; q < QP; ++q) {                                 // branch-free, all loads in flight: see process_tile
-            const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * kNatThreads, P - 1u);
+            const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * NT, P - 1u);
             blk[q] = S.sblk[s];
             pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
         }
@@ -1842,9 +1848,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         uint32_t cnt = 0;
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
-            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            lxq[q] = (int)(blk[q] % NB) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
-            lyq[q] = (int)(blk[q] / NB) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
+            const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * NT;
+            lxq[q] = (int)(blk[q] % NBX) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
+            lyq[q] = (int)(blk[q] / NBX) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
             keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
             mq[q] = __ballot(keep[q]);
             cnt += (uint32_t)__popcll(mq[q]);
@@ -1862,10 +1868,14 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         for (int q = 0; q < QP; ++q)
             if (keep[q]) insert(slot[q], pp[q], pr[q], pid[q], lidq[q], lxq[q], lyq[q], (cc[q] >> 8) & 0xFFu);
     }
-    if (n_exc != 0 && tid < 64) {                                      // stragglers handed to the tile (see process_tile)
-        const bool have = (uint32_t)tid < n_exc;
-        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
+#pragma unroll
+    for (int pi = 0; pi < NPAR; ++pi)
+    if (n_exc[pi] != 0 && tid < 64) {                                  // stragglers handed to the tile (see process_tile)
+        bool have = (uint32_t)tid < n_exc[pi];
+        const uint32_t pt = (uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)(tx * NPAR + pi);
         const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + (have ? (uint32_t)tid : 0u)];
+        // (a cell inside both parents' windows is in both lists: the right-hand list only counts beyond the left one's window)
+        if (pi > 0) have = have && (int)(en.y & 0xFFFFu) > (tx * NPAR + pi - 1) * 32 + 31 + L::HXR;
         uint32_t pid = en.x;
         const float2 pp = A.pos_in[pid];
         const float pr = A.radius[pid];
@@ -1893,17 +1903,17 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     // the tile's own particles and their previous positions: fetched here, used in P6 (as process_tile)
     const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
-    constexpr int QOWN = (L::kSlots + kNatThreads - 1) / kNatThreads;
+    constexpr int QOWN = (L::kSlots + NT - 1) / NT;
     uint32_t own_id[QOWN];
     float2 own_prev[QOWN];
     {
         uint32_t fetch[QOWN];
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
-            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * NT;
             own_id[q] = 0xFFFFFFFFu;
             fetch[q] = 0u;
-            if (q >= 1 && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar)
+            if (q >= 1 && PS <= (uint32_t)q * NT) continue;   // (scalar)
             const uint32_t sc = min(s, PS - 1u);
             const bool own = s < PS && S.own[sc] != 0;
             uint32_t id = S.id[sc];
@@ -1915,7 +1925,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
             own_prev[q] = make_float2(0.f, 0.f);
-            if (q >= 1 && PS <= (uint32_t)q * kNatThreads) continue;
+            if (q >= 1 && PS <= (uint32_t)q * NT) continue;
             if (A.fuse_verlet) own_prev[q] = A.prev[fetch[q]];
         }
     }
@@ -1926,7 +1936,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     {
         constexpr int ZW = ZX / 2, ZH = ZY / 2, QC = ZW * ZH;
         static_assert(QC == QZ && NZ < 4096, "list entries: 12 bits of cell");
-        for (int base = 0; base < QC; base += kNatThreads) {
+        for (int base = 0; base < QC; base += NT) {
             const int i = base + tid;
             const int gx2 = 2 * (i % ZW), gy2 = 2 * (i / ZW);          // zone coordinates of the group's first cell
             int zc[4];
@@ -1944,7 +1954,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             for (int c = 0; c < 4; ++c) {
                 const int lx = gx2 + (c & 1) + L::ZOX, ly = gy2 + (c >> 1) + L::ZOY;   // window coordinates
                 const int gxx = ox + lx, gyy = oy + ly;
-                const int exl = HX - lx, exr = lx - (HX + T - 1), eyl = HY - ly, eyr = ly - (HY + T - 1);
+                const int exl = HX - lx, exr = lx - (HX + TX - 1), eyl = HY - ly, eyr = ly - (HY + TY - 1);
                 const bool in_zone = exl <= kConeLeft - c && exr <= kConeRight - c && eyl <= kConeDown - (c >> 1) &&
                                      eyr <= kConeUp - (c >> 1);
                 const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
@@ -1988,7 +1998,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         const uint32_t nw = min(S.lcnt[8 + k], (uint32_t)L::WC);
         const uint32_t single_base = (group_lanes + 63u) & ~63u;      // waves are all-group or all-single
         const uint32_t work = single_base + ns;
-        for (uint32_t i0 = 0; i0 < work; i0 += kNatThreads) {
+        for (uint32_t i0 = 0; i0 < work; i0 += NT) {
             const uint32_t i = i0 + (uint32_t)tid;
             if (i < group_lanes) {
                 const uint32_t en = S.list[k * QZ + (QZ - 1) - (i / kGroupLanes)];
@@ -2003,7 +2013,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                 resolve_small_cells(S, on, b, n, A.stiffness);
             }
         }
-        for (uint32_t i = (uint32_t)(kNatWaves - 1 - (tid >> 6)); i < nw; i += kNatWaves) {     // wave-uniform
+        for (uint32_t i = (uint32_t)(NW - 1 - (tid >> 6)); i < nw; i += NW) {     // wave-uniform
             // a cell of 7..64 members: its first six from its own slots, the others from the side list, into the wave's
             // scratch run of the member array; then the whole-wave walk
             const uint32_t zc = S.wlist[k * L::WC + i];
@@ -2032,7 +2042,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     for (int q = 0; q < QOWN; ++q) {
         const uint32_t id = own_id[q];
         if (id == 0xFFFFFFFFu) continue;
-        const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+        const uint32_t s = (uint32_t)tid + (uint32_t)q * NT;
         const float2 c = make_float2(S.px[s], S.py[s]);
         if (A.fuse_verlet && id < n_owned) {
             float2 o;
@@ -2054,19 +2064,29 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #ifndef GPE_CAP_DIRECT_ORD
 #define GPE_CAP_DIRECT_ORD 752
 #endif
-template <int T, int CAP, bool ORD>
-__global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide_direct(CollideArgs A)
+#ifndef GPE_CAP_WIDE
+#define GPE_CAP_WIDE 2176
+#endif
+#ifndef GPE_CAP_WIDE_ORD
+#define GPE_CAP_WIDE_ORD 1760
+#endif
+// TX x 32-cell tiles on NT threads: 32 x 32 on 512 (four workgroups per CU), or 64 x 32 on 1024 (two per CU; the window
+// is 1.32 x the tile's own cells instead of 1.48 x, the looked-up blocks 1.875 x instead of 2.25 x).  A tile the
+// window has no room for is listed for k_collide_overflow as its 32 x 32 tile(s).
+template <int TX, int CAP, bool ORD, int NT>
+__global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
 {
-    __shared__ TileDirect<T, CAP, ORD> S;
+    __shared__ TileDirect<TX, 32, CAP, ORD, NT> S;
     const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
     const uint32_t per_xcd = (total + 7u) / 8u;
     const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
     const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
     if (!process_tile_direct<ORD>(S, A, tx, ty)) {
-        if (threadIdx.x == 0) {
+        const uint32_t ptx = (uint32_t)tx * (TX / 32) + threadIdx.x;
+        if (threadIdx.x < TX / 32 && (TX == 32 || (int)ptx * 32 < A.gx)) {      // (a wide tile's right half may lie outside the box)
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
-            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | ptx;
             else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
         }
     }
@@ -2544,11 +2564,21 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
             else
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        } else if ((c->cfg.flags & GPE_FLAG_WIDE_TILES) != 0) {
+            // 64 x 32-cell tiles: the tile grid in x is that of 64-cell columns
+            CollideArgs W = A;
+            W.tile_x0 = cx0 / 64;
+            W.tiles_x = cx1 / 64 - W.tile_x0 + 1;
+            const uint32_t wgrid = (((uint32_t)W.tiles_x * (uint32_t)W.tiles_y + 7u) / 8u) * 8u;
+            if (A.order_keys)
+                hipLaunchKernelGGL((k_collide_direct<64, GPE_CAP_WIDE_ORD, true, 1024>), dim3(wgrid), dim3(1024), 0, c->stream, W);
+            else
+                hipLaunchKernelGGL((k_collide_direct<64, GPE_CAP_WIDE, false, 1024>), dim3(wgrid), dim3(1024), 0, c->stream, W);
         } else {
             if (A.order_keys)
-                hipLaunchKernelGGL((k_collide_direct<kTileMain, GPE_CAP_DIRECT_ORD, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
             else
-                hipLaunchKernelGGL((k_collide_direct<kTileMain, GPE_CAP_DIRECT, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         }
         GPE_HIP(c, hipGetLastError());
     }

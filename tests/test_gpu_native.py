@@ -594,3 +594,35 @@ def test_pipeline_info_reports_mode_table_and_default(gpe):
     i = ctx.pipeline_info()
     assert (i["pipeline"], i["reason"]) == (L.PIPELINE_COMPAT, L.REASON_NO_PARTICLES), i
     ctx.close()
+
+
+@pytest.mark.parametrize("flag", ["FLAG_WIDE_TILES", "FLAG_COUNTING_SORT_TILES"])
+def test_other_tile_forms_give_the_same_bits(gpe, oracle, flag):
+    """The dense launch has three forms of its tile -- 32 x 32 cells with direct cell slots (the default), the same
+    tile with counting-sort member lists (rounds 1-2, GPE_FLAG_COUNTING_SORT_TILES) and 64 x 32 cells on 1024 threads
+    (GPE_FLAG_WIDE_TILES; measured slower, kept for the record): bit-identical to each other and to the oracle, with
+    gravity moving the cloud across tile boundaries, stragglers, a re-sort, and a crowded corner whose windows the wide
+    tile hands to the over-capacity launch."""
+    n = 150_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=17)
+    rng = np.random.default_rng(18)
+    pos[:4000] = (rng.random((4000, 2), dtype=np.float32) * np.float32(40.0) + np.float32(3.0)).astype(np.float32)   # 2.5 / unit^2
+    g = (3.0, -9.81)
+    a = gpe.State(pos, rad, world=world, gravity=g)
+    b = gpe.State(pos, rad, world=world, gravity=g, flags=getattr(gpe._lib, flag))
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5, gravity=g))
+    oracle.set_threads(8)
+    try:
+        for s in range(40):
+            rs = s in (0, 25)
+            a.update(1 / 60, resort=rs); b.update(1 / 60, resort=rs); sim.step(1 / 60, resort=rs)
+            if s % 8 == 7 or s in (0, 25, 39):
+                pa = a.positions()
+                assert np.array_equal(pa, b.positions()), "%s, step %d" % (flag, s)
+                _assert_positions(pa, sim.pos, "default tiles vs oracle, step %d" % s)
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(a.previous_positions(), b.previous_positions())
+    a.ctx.sync(); b.ctx.sync()
+    a.close(); b.close(); sim.close()
