@@ -245,6 +245,7 @@ struct OnesweepWorkspace {
     uint64_t status_cap = 0;
     uint32_t *hist4 = nullptr;       // 4 x 256 digit histograms
     uint32_t *bases4 = nullptr;      // 4 x 256 exclusive digit bases
+    uint32_t *hist_plain = nullptr;  // 4 x 256: histograms of the sorts whose producer brings none
     uint32_t *ctl = nullptr;         // [0..3] tile tickets per pass, [4] error word
     uint32_t epoch = 0;
     bool hist_clean = false;         // the set the next native step adds into is zero: the native step keeps it so
@@ -265,6 +266,13 @@ struct NativeState {
     uint32_t *keys_b = nullptr, *ids_b = nullptr;   // sort pong
     uint64_t cap = 0;
     uint32_t *codes = nullptr;       // per particle: cell relative to its sorted block | neighbour overlap mask | straggler (k_native_hash)
+    uint32_t *gkeys = nullptr, *gids = nullptr, *gkeys_b = nullptr, *gids_b = nullptr;   // sharded runs: the ghosts' sort
+    uint64_t gcap = 0;
+    uint2 *gtable = nullptr;         // ... and their block table
+    uint32_t *ghist = nullptr;       // ... and its digit histograms (two sets of kHistCopies copies, like os_ws.hist4)
+    uint32_t ghist_set = 0;
+    uint64_t gtable_cap = 0;
+    const uint32_t *gsorted_ids_now = nullptr;   // the ghosts' indices in block order, this step (NULL: no ghost table)
     uint32_t *exc_count = nullptr;   // straggler lists: [2][exc_tiles] counts, then [2][exc_tiles][16] entries (one allocation)
     uint2 *exc_entry = nullptr;
     uint64_t exc_tiles = 0, exc_cap = 0;
@@ -459,6 +467,9 @@ struct OnesweepGate {
     uint64_t table_pairs = 0;
     uint32_t *fresh = nullptr;
     uint32_t *sorts = nullptr;
+    int ticket_base = 0;                   // tile tickets at ctl[ticket_base + pass]
+    const uint32_t *count_now = nullptr;   // first pass: *sorted_count = *count_now (NULL: n) -- the particles the grouping covers
+    uint32_t *sorted_count = nullptr;
 };
 gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *keys_b, uint32_t *vals_b,
                          uint64_t n, int passes, bool hist_ready, bool iota_vals, uint32_t **out_keys,

@@ -94,6 +94,8 @@ constexpr int kCtlNeedSort = 10;               // [parity] the hash found a part
 constexpr int kCtlFresh = 12;                  // [parity] the radix passes ran: the block table describes THIS step's positions
 constexpr int kCtlSorts = kNativeCtlSorts;     // steps whose radix passes ran (running count, gpe_get_pipeline_info)
 constexpr int kCtlStragglers0 = 9, kCtlStragglers1 = 15;   // [parity] stragglers found by the step's hash so far
+constexpr int kCtlSortedCount = 16;            // particles the kept grouping covers (written by the first radix pass)
+constexpr int kCtlWords = 32;                  // tile_ctl is this long
 // How far a particle may have left the 8x8-cell block it was sorted into (cells beyond the block's extent, per
 // direction) and still be found by every tile that needs it.  A tile looks up the blocks of tile +- 8 cells but keeps
 // only the window [x0-5, x1+4] x [y0-3, y1+2] (kCone* + 1): a kept particle that moved right by dr cells comes from a
@@ -189,6 +191,18 @@ __device__ __forceinline__ uint32_t neighbour_overlap_mask(float2 p, float r, in
 // HBM: two workgroups per CU (64 VGPRs: two positions per lane in flight instead of eight) and up to 2048 of them
 // take it from 544 to 454 us at 100 M particles and from 98 to 84 us at 16 M, the extra flushes included
 // (profiles/r02/ab_hash_occupancy.txt).
+// Sharded runs with the counts on the device (k_shard.hip): the first *owned particles are the rank's own and take
+// part in the kept grouping; the ghosts behind them change every step, so they are grouped by a small sort of their
+// own every step (gkeys / gids, g_bound pairs, the ghost block table).  All NULL / 0 otherwise.
+struct HashGhosts {
+    const uint32_t *owned = nullptr;
+    uint32_t *gkeys = nullptr, *gids = nullptr;
+    uint64_t g_bound = 0;
+    uint4 *gtable2 = nullptr;
+    uint64_t gtable_pairs = 0;
+    const uint32_t *sorted_count = nullptr;    // tile_ctl[kCtlSortedCount]
+    uint32_t *ghist_now = nullptr, *ghist_next = nullptr;   // the ghost sort's digit histograms (kHistCopies copies, two sets)
+};
 constexpr int kHashBlock = 1024;
 constexpr int kHashBatch = 2;                  // positions loaded per lane before any of them is ranked
 constexpr int kHashGridMax = 2048;
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                                                             uint64_t div_magic, uint32_t *__restrict__ exc_count,
                                                             uint2 *__restrict__ exc_entry,
                                                             uint32_t *__restrict__ exc_count_next, int32_t exc_tiles_x,
-                                                            int32_t exc_tiles_y, uint32_t straggler_limit)
+                                                            int32_t exc_tiles_y, uint32_t straggler_limit, HashGhosts G)
 {
     // sorted_key[i] = the block key particle i had when the radix passes last ran (they keep it up to date,
     // k_onesweep.hip): the sorted ids and the block table still describe THAT grouping.  As long as every particle
@@ -218,7 +232,9 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     // parity]; the radix passes that follow look at the word and return at once when it is 0.
     // sorted_key == NULL: always sort (first step, sharded runs, one-pass sorts).
     __shared__ uint32_t s_hist[4 * 256];
+    __shared__ uint32_t s_ghist[4 * 256];                              // (the ghosts' keys, sharded runs)
     s_hist[threadIdx.x] = 0;
+    s_ghist[threadIdx.x] = 0;
     // What a step accumulates into is reset here instead of by a launch of its own (a launch costs ~6 us, 5 % of
     // the step at 1 M particles): the block table (filled two kernels later), and -- workgroup 0 -- the per-step
     // control words, after handing the previous step's window statistic to the host (pinned memory), the radix
@@ -226,6 +242,8 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     // this step's set is read by the radix passes that follow, nobody touches the other one meanwhile).
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         table2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);      // (first, one past last) = (max, 0): empty
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.gtable_pairs; i += (uint64_t)gridDim.x * blockDim.x)
+        G.gtable2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);   // the ghosts' block table: rebuilt every step
     if (exc_count_next) {                                              // the next step's straggler lists
         const uint64_t nt = (uint64_t)exc_tiles_x * (uint64_t)exc_tiles_y;
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (uint64_t)gridDim.x * blockDim.x)
@@ -243,7 +261,9 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     }
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kHashBlock) hist_next[i] = 0;
-        if (threadIdx.x < 8) os_ctl[threadIdx.x] = 0;                  // tile tickets + error word
+        if (G.ghist_next)
+            for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kHashBlock) G.ghist_next[i] = 0;
+        if (threadIdx.x < 16) os_ctl[threadIdx.x] = 0;                 // tile tickets (owned [0..3], ghosts [8..11]) + error word [4]
         if (threadIdx.x == 0) {                                        // the next step's words; this step's if it must sort
             tile_ctl[kCtlNeedSort + (parity ^ 1u)] = 0;
             tile_ctl[kCtlFresh + (parity ^ 1u)] = 0;
@@ -260,6 +280,18 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     if (n_valid_ptr) {
         nv = *n_valid_ptr;
         if (nv > n) { nv = n; if (threadIdx.x == 0) atomicOr(&tile_ctl[kCtlError], kErrBoundExceeded); }
+    }
+    // owned particles [0, n_own), ghosts [n_own, nv); indices from sorted_cnt on are not in the kept grouping
+    uint64_t n_own = nv;
+    if (G.owned) n_own = min((uint64_t)*G.owned, nv);
+    const uint64_t sorted_cnt = (sorted_key && G.sorted_count) ? (uint64_t)*G.sorted_count : ~0ull;
+    if (G.gkeys) {
+        // ghost slots behind the last one the particle loop below reaches: padding (sorts behind every block)
+        const uint64_t first = n - n_own;
+        for (uint64_t j = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G.g_bound; j += (uint64_t)gridDim.x * blockDim.x) {
+            G.gkeys[j] = pad_key; G.gids[j] = 0u;
+        }
+        if (nv - n_own > G.g_bound && threadIdx.x == 0) atomicOr(&tile_ctl[kCtlError], kErrBoundExceeded);
     }
     bool oob = false, drifted = false;
     for (uint64_t r0 = 0; r0 < rounds; r0 += kHashBatch) {
@@ -280,7 +312,13 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
             if (r0 + u >= rounds) break;                               // wave-uniform
             const bool valid = idx[u] < n;
             uint32_t key = pad_key;
-            if (valid && idx[u] >= nv) { keys[idx[u]] = pad_key; codes[idx[u]] = 0u; }
+            if (valid && idx[u] >= nv) {
+                keys[idx[u]] = pad_key; codes[idx[u]] = 0u;
+                if (G.gkeys && idx[u] - n_own < G.g_bound) { G.gkeys[idx[u] - n_own] = pad_key; G.gids[idx[u] - n_own] = 0u; }
+            }
+            const bool ghost = idx[u] >= n_own;
+            uint32_t gkey = 0;
+            bool gvalid = false;
             if (idx[u] < nv) {
                 const int32_t cx = cell_coord(p[u].x, cell_size), cy = cell_coord(p[u].y, cell_size);
                 // the particle's 8x8-cell block, row-major over the block box (0 for a particle outside it: flagged)
@@ -289,18 +327,27 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                                  (lby < 0) | (lby >= blocks_y);
                 oob |= out;
                 key = out ? 0u : (uint32_t)(lby * blocks_x + lbx);
+                if (ghost && G.gkeys) {
+                    // a ghost: grouped by the ghosts' own sort; in the owned particles' sort it is padding
+                    const uint64_t j = idx[u] - n_own;
+                    if (j < G.g_bound) { G.gkeys[j] = key; G.gids[j] = (uint32_t)idx[u]; gkey = key; gvalid = true; }
+                    key = pad_key;
+                }
                 keys[idx[u]] = key;
                 // The particle's cell relative to the first cell of the block it was SORTED into (== its block of now
                 // when the passes run this step: then the tiles take the value mod 8).  okey / blocks_x by a 64-bit
                 // multiply: exact for okey * blocks_x < 2^40 (keys < 2^27, blocks_x <= 2^13).
                 int32_t relx = cx & 7, rely = cy & 7;
                 bool straggler = false;
-                if (sorted_key) {
+                if (sorted_key && !(ghost && G.gkeys)) {
                     const uint32_t oby = (uint32_t)(((uint64_t)okey[u] * div_magic) >> 40);
                     const uint32_t obx = okey[u] - oby * (uint32_t)blocks_x;
                     relx = cx - (int32_t)((obx + (uint32_t)bx0) << 3);
                     rely = cy - (int32_t)((oby + (uint32_t)by0) << 3);
-                    straggler = !out && ((relx < -kDriftLeft) | (relx > 7 + kDriftRight) | (rely < -kDriftDown) | (rely > 7 + kDriftUp));
+                    // out of reach of its old block, or not in the kept grouping at all (an arrival of a sharded run,
+                    // filed behind the particles the last sort covered): handed to the tiles directly
+                    straggler = !out && ((relx < -kDriftLeft) | (relx > 7 + kDriftRight) | (rely < -kDriftDown) | (rely > 7 + kDriftUp) |
+                                         (idx[u] >= sorted_cnt));
                 }
                 // what the tiles need to file the particle: that relative cell and its phantom cells.
                 // Computed once here instead of by each of the ~2.25 tiles that stage the particle.
@@ -334,7 +381,17 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q < digits) hist_add(s_hist + q * 256, (key >> (8 * q)) & 255u, valid);
+            if (G.gkeys) {                                             // (uniform)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < digits) hist_add(s_ghist + q * 256, (gkey >> (8 * q)) & 255u, gvalid);
+            }
         }
+    }
+    if (G.gkeys && blockIdx.x == 0 && threadIdx.x < (uint32_t)digits) {
+        // the ghost sort covers g_bound slots: those behind the ghosts hold the padding key
+        const uint64_t ng = min(nv - n_own, G.g_bound);
+        atomicAdd(&s_ghist[threadIdx.x * 256 + ((pad_key >> (8 * threadIdx.x)) & 255u)], (uint32_t)(G.g_bound - ng));
     }
     if (oob) atomicOr(&tile_ctl[kCtlError], kErrOutOfBox);
     if (__ballot(drifted) != 0 && lane_id() == 0) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
@@ -348,6 +405,13 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
             __hip_atomic_fetch_add(
                 reinterpret_cast<unsigned long long *>(&hist4[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
                 (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (G.ghist_now) {
+            const uint32_t glo = s_ghist[threadIdx.x], ghi = s_ghist[threadIdx.x + 1];
+            if (glo | ghi)
+                __hip_atomic_fetch_add(
+                    reinterpret_cast<unsigned long long *>(&G.ghist_now[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
+                    (unsigned long long)glo | ((unsigned long long)ghi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -417,6 +481,8 @@ struct CollideArgs {
     const uint32_t *sorted_ids;
     const uint32_t *codes;       // per particle: cell relative to the block it was sorted into (4 + 4 bits, biased by
                                  // kDriftLeft / kDriftDown) | neighbour overlap mask (8 bits) | kCodeStraggler
+    const uint2 *gtable;         // sharded runs: (start, end) of every block among the GHOSTS, sorted every step (else NULL)
+    const uint32_t *gsorted_ids; // ... and their particle indices in that order
     const uint32_t *exc_count;   // stragglers handed to each 32x32 tile this step (NULL: none, the run always sorts)
     const uint2 *exc_entry;      // kExcSlots x (particle, cell x | y << 16) per tile
     int32_t exc_tiles_x;
@@ -536,9 +602,12 @@ struct TileLds {
     static constexpr int WC = T >= 32 ? 16 : 64;
     uint16_t wlist[4 * WC];
     uint32_t lcnt[12];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave
-    uint32_t bstart[NBLK];
-    uint32_t bcnt[NBLK];
-    uint32_t boff[NBLK + 1];
+    // looked-up blocks; an order-key (sharded) window looks every block up twice: among the owned particles (the kept
+    // table) and among the ghosts (their own table, rebuilt every step): virtual blocks [NBLK, 2 NBLK)
+    static constexpr int VBMAX = (kLid || kGlobal) ? 2 * NBLK : NBLK;
+    uint32_t bstart[VBMAX];
+    uint32_t bcnt[VBMAX];
+    uint32_t boff[VBMAX + 1];
     uint32_t s_w[16];
     uint32_t misc[4];
 };
@@ -577,9 +646,12 @@ struct TileGlobal {
     static constexpr int WC = 64;
     uint16_t wlist[4 * WC];
     uint32_t lcnt[12];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave
-    uint32_t bstart[NBLK];
-    uint32_t bcnt[NBLK];
-    uint32_t boff[NBLK + 1];
+    // looked-up blocks; an order-key (sharded) window looks every block up twice: among the owned particles (the kept
+    // table) and among the ghosts (their own table, rebuilt every step): virtual blocks [NBLK, 2 NBLK)
+    static constexpr int VBMAX = (kLid || kGlobal) ? 2 * NBLK : NBLK;
+    uint32_t bstart[VBMAX];
+    uint32_t bcnt[VBMAX];
+    uint32_t boff[VBMAX + 1];
     uint32_t s_w[16];
     uint32_t misc[4];
 };
@@ -1060,7 +1132,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 {
     constexpr int T = L::TILE;
     constexpr int RWX = L::RWX, RWY = L::RWY, PX = L::PX, NCELL = L::NCELL, NB = L::NB, NBLK = L::NBLK, PER = L::PER, QMAX = L::QMAX;
-    static_assert(NBLK <= 255, "sblk is 8 bit");
+    // virtual blocks: an order-key (sharded) window looks every block up among the owned particles AND among the ghosts
+    constexpr int VB = ORD ? 2 * NBLK : NBLK;
+    static_assert(VB <= 255 && VB <= L::VBMAX, "sblk is 8 bit; the lookup arrays hold the virtual blocks");
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     constexpr int HX = L::HXL, HY = L::HYL;                            // cells kept left of / below the tile
@@ -1072,15 +1146,17 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
     S.cell_clear(tid);
     if (tid < 12) S.lcnt[tid] = 0;
-    if (tid < NBLK) {
-        const int bi = tid % NB, bj = tid / NB;
+    if (tid < VB) {
+        const int rb = tid % NBLK;                                     // the block; tid >= NBLK: among the ghosts
+        const int bi = rb % NB, bj = rb / NB;
         const int bx = box + bi, by = boy + bj;
         uint32_t start = 0, count = 0;
         const int lbx = bx - A.bx0, lby = by - A.by0;
-        if (lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
+        const uint2 *tab = (ORD && tid >= NBLK) ? A.gtable : A.table;
+        if (tab && lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
             const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
             if (mb < A.entries) {
-                const uint2 se = A.table[mb];                        // empty blocks hold (0xFFFFFFFF, 0)
+                const uint2 se = tab[mb];                            // empty blocks hold (0xFFFFFFFF, 0)
                 if (se.y > se.x) { start = se.x; count = se.y - se.x; }
             }
         }
@@ -1091,20 +1167,20 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     if (tid < 64) {
         // exclusive scan of the block populations by one wave; particles of the tile's own blocks
         uint32_t carry = 0, own = 0;
-        for (int base = 0; base < NBLK; base += 64) {
+        for (int base = 0; base < VB; base += 64) {
             const int b = base + lane;
-            const uint32_t cb = (b < NBLK) ? S.bcnt[b] : 0u;
+            const uint32_t cb = (b < VB) ? S.bcnt[b] : 0u;
             const uint32_t inc = wave_inclusive_scan(cb);
-            if (b < NBLK) {
+            if (b < VB) {
                 S.boff[b] = carry + inc - cb;
-                const int bi = b % NB, bj = b / NB;
+                const int bi = (b % NBLK) % NB, bj = (b % NBLK) / NB;
                 if (bi >= 1 && bi < NB - 1 && bj >= 1 && bj < NB - 1) own += cb;
             }
             carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         own = wave_sum(own);
         if (lane == 0) {
-            S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[1] = own; S.misc[3] = 0;
+            S.boff[VB] = carry; S.misc[0] = carry; S.misc[1] = own; S.misc[3] = 0;
             if (!L::kGlobal) S.misc[2] = 0;                            // main tile: "a cell of more than 64 members"
         }
     } else if (tid < 64 + (NB - 2) * (NB - 2)) {
@@ -1125,6 +1201,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     if (P == 0) return true;
     // (relative cell -> cell inside the block when the table is of this step: the value mod 8; else unchanged)
     const bool stale = __builtin_amdgcn_readfirstlane((int)*A.fresh) == 0;
+    const uint32_t n_owned_now = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
     const int rel_mask = stale ? -1 : 7;
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;       // (listed under a block it is out of reach of: skipped)
     // stragglers handed to this tile's 32x32 parent by the hash kernel (P1 files them behind the looked-up particles)
@@ -1150,8 +1228,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     }
     {
         // slot -> block map: kNatThreads / NBLK threads share each block's slots
-        constexpr int SHARE = (kNatThreads / NBLK) > 0 ? (kNatThreads / NBLK) : 1;
-        for (int b = tid % NBLK, sub = tid / NBLK; sub < SHARE && b < NBLK; b += kNatThreads) {
+        constexpr int SHARE = (kNatThreads / VB) > 0 ? (kNatThreads / VB) : 1;
+        for (int b = tid % VB, sub = tid / VB; sub < SHARE && b < VB; b += kNatThreads) {
             const uint32_t lo = S.boff[b], hi = S.boff[b + 1];
             for (uint32_t i = lo + sub; i < hi; i += SHARE) S.sblk[i] = (uint8_t)b;
         }
@@ -1177,7 +1255,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             // and are discarded by `keep` below.  (P >= 1: see P0.)
             const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * kNatThreads, P - 1u);
             blk[q] = S.sblk[s];
-            pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
+            const uint32_t *ids = (ORD && blk[q] >= (uint32_t)NBLK) ? A.gsorted_ids : A.sorted_ids;
+            pid[q] = ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
         }
 #ifdef GPE_TILE_STAMPS
         { uint32_t acc = 0; for (int q = 0; q < QP; ++q) acc += pid[q]; asm volatile("" :: "v"(acc)); }
@@ -1210,9 +1289,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            lxq[q] = (int)(blk[q] % NB) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
-            lyq[q] = (int)(blk[q] / NB) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
+            const uint32_t rb = ORD ? blk[q] % (uint32_t)NBLK : blk[q];
+            lxq[q] = (int)(rb % NB) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
+            lyq[q] = (int)(rb / NB) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
             keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
+            // (an order-key window: the kept table may still list indices the owned range has shrunk below -- those
+            // particles are ghosts now, or gone: they come through the ghosts' table, or not at all)
+            if constexpr (ORD) keep[q] = keep[q] && (A.gtable == nullptr || blk[q] >= (uint32_t)NBLK || lidq[q] < n_owned_now);
             slot[q] = s;
         }
         if constexpr (kTrim) {
@@ -1579,12 +1662,12 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if constexpr (ORD) {                                       // S.id holds the order key: find the block of
                 const uint32_t raw = s;                                // the looked-up slot, re-read the local index
-                int lo = 0, hi = NBLK;
+                int lo = 0, hi = VB;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (S.boff[mid] <= raw) lo = mid; else hi = mid;
                 }
-                id = A.sorted_ids[S.bstart[lo] + (raw - S.boff[lo])];
+                id = (lo >= NBLK ? A.gsorted_ids : A.sorted_ids)[S.bstart[lo] + (raw - S.boff[lo])];
             }
             const float2 c = make_float2(S.px[s], S.py[s]);
             if (A.fuse_verlet && id < n_owned) {
@@ -1701,9 +1784,10 @@ struct TileDirect {
     uint16_t wlist[4 * WC];    // cells of more than kDirectSlots members, per colour
     uint32_t big[kBigCap];     // memberships that found their cell's slots taken: zone cell << 16 | particle slot
     uint32_t lcnt[12];
-    uint32_t bstart[NBLK];
-    uint32_t bcnt[NBLK];
-    uint32_t boff[NBLK + 1];
+    static constexpr int VBMAX = kLid ? 2 * NBLK : NBLK;  // (see TileLds: owned and ghost lookups of an order-key window)
+    uint32_t bstart[VBMAX];
+    uint32_t bcnt[VBMAX];
+    uint32_t boff[VBMAX + 1];
     uint32_t s_w[16];
     uint32_t misc[6];          // [0] looked up, [2] hand the tile on, [3] kept, [4] side-list entries
 };
@@ -1713,6 +1797,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 {
     constexpr int TX = L::TX, TY = L::TY, NT = L::NT, NW = L::NW;
     constexpr int RWX = L::RWX, RWY = L::RWY, NBX = L::NBX, NBY = L::NBY, NBLK = L::NBLK, QMAX = L::QMAX;
+    constexpr int VB = ORD ? 2 * NBLK : NBLK;                          // (owned and ghost lookups: see process_tile)
+    static_assert(VB <= 255 && VB <= L::VBMAX, "sblk is 8 bit; the lookup arrays hold the virtual blocks");
     constexpr int ZX = L::ZX, ZY = L::ZY, NZ = L::NZ, QZ = L::QZ;
     constexpr int HX = L::HXL, HY = L::HYL;
     const int tid = (int)threadIdx.x;
@@ -1724,14 +1810,16 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     // ---- P0: clear the counters, look the region's blocks up, slot -> block map (as process_tile) ------------------
     for (int i = tid; i < (NZ + 1) / 2; i += NT) S.cntw[i] = 0;
     if (tid < 12) S.lcnt[tid] = 0;
-    if (tid < NBLK) {
-        const int bi = tid % NBX, bj = tid / NBX;
+    if (tid < VB) {
+        const int rb = tid % NBLK;
+        const int bi = rb % NBX, bj = rb / NBX;
         const int lbx = box + bi - A.bx0, lby = boy + bj - A.by0;
         uint32_t start = 0, count = 0;
-        if (lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
+        const uint2 *tab = (ORD && tid >= NBLK) ? A.gtable : A.table;
+        if (tab && lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
             const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
             if (mb < A.entries) {
-                const uint2 se = A.table[mb];                        // empty blocks hold (0xFFFFFFFF, 0)
+                const uint2 se = tab[mb];                            // empty blocks hold (0xFFFFFFFF, 0)
                 if (se.y > se.x) { start = se.x; count = se.y - se.x; }
             }
         }
@@ -1741,14 +1829,14 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     __syncthreads();
     if (tid < 64) {
         uint32_t carry = 0;
-        for (int base = 0; base < NBLK; base += 64) {
+        for (int base = 0; base < VB; base += 64) {
             const int b = base + lane;
-            const uint32_t cb = (b < NBLK) ? S.bcnt[b] : 0u;
+            const uint32_t cb = (b < VB) ? S.bcnt[b] : 0u;
             const uint32_t inc = wave_inclusive_scan(cb);
-            if (b < NBLK) S.boff[b] = carry + inc - cb;
+            if (b < VB) S.boff[b] = carry + inc - cb;
             carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
-        if (lane == 0) { S.boff[NBLK] = carry; S.misc[0] = carry; S.misc[2] = 0; S.misc[3] = 0; S.misc[4] = 0; }
+        if (lane == 0) { S.boff[VB] = carry; S.misc[0] = carry; S.misc[2] = 0; S.misc[3] = 0; S.misc[4] = 0; }
     } else if (tid < 64 + (NBX - 2) * (NBY - 2)) {
         const int wi = (tid - 64) % (NBX - 2), wj = (tid - 64) / (NBX - 2);
         uint32_t w = 0;
@@ -1762,6 +1850,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);
     if (P == 0) return true;
     const bool stale = __builtin_amdgcn_readfirstlane((int)*A.fresh) == 0;
+    const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
     const int rel_mask = stale ? -1 : 7;
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
     // stragglers: the lists of the 32x32 tiles this tile covers (one, or two side by side for a 64-cell-wide tile)
@@ -1777,8 +1867,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     }
     if (P > (uint32_t)L::RAWCAP) return false;                         // more looked-up particles than slots
     {
-        constexpr int SHARE = (NT / NBLK) > 0 ? (NT / NBLK) : 1;
-        for (int b = tid % NBLK, sub = tid / NBLK; sub < SHARE && b < NBLK; b += NT) {
+        constexpr int SHARE = (NT / VB) > 0 ? (NT / VB) : 1;
+        for (int b = tid % VB, sub = tid / VB; sub < SHARE && b < VB; b += NT) {
             const uint32_t lo = S.boff[b], hi = S.boff[b + 1];
             for (uint32_t i = lo + sub; i < hi; i += SHARE) S.sblk[i] = (uint8_t)b;
         }
@@ -1826,7 +1916,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         for (int q = 0; q < QP; ++q) {                                 // branch-free, all loads in flight: see process_tile
             const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * NT, P - 1u);
             blk[q] = S.sblk[s];
-            pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
+            const uint32_t *ids = (ORD && blk[q] >= (uint32_t)NBLK) ? A.gsorted_ids : A.sorted_ids;
+            pid[q] = ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
         }
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
@@ -1849,9 +1940,11 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * NT;
-            lxq[q] = (int)(blk[q] % NBX) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
-            lyq[q] = (int)(blk[q] / NBX) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
+            const uint32_t rb = ORD ? blk[q] % (uint32_t)NBLK : blk[q];
+            lxq[q] = (int)(rb % NBX) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
+            lyq[q] = (int)(rb / NBX) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
             keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
+            if constexpr (ORD) keep[q] = keep[q] && (A.gtable == nullptr || blk[q] >= (uint32_t)NBLK || lidq[q] < n_owned);   // (see process_tile)
             mq[q] = __ballot(keep[q]);
             cnt += (uint32_t)__popcll(mq[q]);
         }
@@ -1901,8 +1994,6 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     if (n_big > (uint32_t)kBigCap) return false;                       // crowded cells: process_tile's windows take it
 
     // the tile's own particles and their previous positions: fetched here, used in P6 (as process_tile)
-    const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
     constexpr int QOWN = (L::kSlots + NT - 1) / NT;
     uint32_t own_id[QOWN];
     float2 own_prev[QOWN];
@@ -2061,14 +2152,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #ifndef GPE_CAP_DIRECT
 #define GPE_CAP_DIRECT 928
 #endif
-#ifndef GPE_CAP_DIRECT_ORD
-#define GPE_CAP_DIRECT_ORD 752
-#endif
 #ifndef GPE_CAP_WIDE
 #define GPE_CAP_WIDE 2176
-#endif
-#ifndef GPE_CAP_WIDE_ORD
-#define GPE_CAP_WIDE_ORD 1760
 #endif
 // TX x 32-cell tiles on NT threads: 32 x 32 on 512 (four workgroups per CU), or 64 x 32 on 1024 (two per CU; the window
 // is 1.32 x the tile's own cells instead of 1.48 x, the looked-up blocks 1.875 x instead of 2.25 x).  A tile the
@@ -2164,6 +2249,12 @@ void native_release(gpe_ctx *c)
     if (N.codes) (void)hipFree(N.codes);
     if (N.sorted_key) (void)hipFree(N.sorted_key);
     if (N.exc_count) (void)hipFree(N.exc_count);
+    if (N.gkeys) (void)hipFree(N.gkeys);
+    if (N.gids) (void)hipFree(N.gids);
+    if (N.gkeys_b) (void)hipFree(N.gkeys_b);
+    if (N.gids_b) (void)hipFree(N.gids_b);
+    if (N.gtable) (void)hipFree(N.gtable);
+    if (N.ghist) (void)hipFree(N.ghist);
     if (N.ids) (void)hipFree(N.ids);
     if (N.keys_b) (void)hipFree(N.keys_b);
     if (N.ids_b) (void)hipFree(N.ids_b);
@@ -2199,10 +2290,36 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     const uint32_t parity = (N.step_seq++) & 1u;
     // The kept grouping can be used when it belongs to these particles and this box.  Sharded runs (ghosts come and go
     // every step, padding keys) and one-pass sorts (the table would be reset and filled by the same launch) always sort.
+    // A sharded run with its counts on the device (k_shard.hip) keeps the grouping of its OWNED particles the same way:
+    // their indices are stable (a hole left by a migrant is filled from the tail, an arrival is appended: both reach
+    // the tiles as stragglers until the next sort), while the ghosts -- new every step -- are grouped by a small sort
+    // of their own, every step, into a second block table.  Other sharded set-ups (host-side counts) always sort.
     const bool sharded = c->shard.on || c->use_order_keys || c->has_active_box;
-    const bool gated = N.passes >= 2 && !sharded;
-    const bool reuse = gated && !always_sort && N.sort_state_valid && N.sorted_n == n && !N.always_sort;
+    const bool kept_sharded = c->shard.on && c->shard.active && c->use_order_keys && N.gkeys != nullptr && !N.always_sort;
+    const bool gated = N.passes >= 2 && (!sharded || kept_sharded);
+    const bool reuse = gated && !always_sort && N.sort_state_valid && (kept_sharded || N.sorted_n == n) && !N.always_sort;
     const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;        // the table is allocated in 16-byte units
+    HashGhosts hg;
+    hg.sorted_count = N.tile_ctl + kCtlSortedCount;
+    uint64_t g_bound = 0;
+    if (kept_sharded) {
+        // upper bound of the ghost count from the pinned mirror (lags by the steps in flight), as for the total
+        const ShardState &SH = c->shard;
+        g_bound = c->cap;
+        const uint32_t epoch = __atomic_load_n(&SH.host_counts[kShardEpoch], __ATOMIC_ACQUIRE);
+        if ((int32_t)(epoch - SH.begin_epoch) > 0) {
+            const uint64_t gh = SH.host_counts[kShardTotal] >= SH.host_counts[kShardOwned]
+                                    ? SH.host_counts[kShardTotal] - SH.host_counts[kShardOwned] : 0;
+            g_bound = std::min<uint64_t>(c->cap, gh + std::max<uint64_t>(16384, gh / 4));
+        }
+        g_bound = std::min<uint64_t>(g_bound, n);
+        hg.owned = SH.counts + kShardOwned;
+        hg.gkeys = N.gkeys; hg.gids = N.gids; hg.g_bound = g_bound;
+        hg.gtable2 = (uint4 *)N.gtable; hg.gtable_pairs = pairs;
+        hg.ghist_now = N.ghist + (size_t)N.ghist_set * kHistSet;       // (two sets, alternating over the steps that use them:
+        hg.ghist_next = N.ghist + (size_t)(N.ghist_set ^ 1u) * kHistSet;   //  this step's hash zeroes the next one's)
+        N.ghist_set ^= 1u;
+    }
     {
         Scope s(c, "native/hash");
         // at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
@@ -2216,7 +2333,8 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
                            N.host_stat, reuse ? N.sorted_key : nullptr, parity, div_magic,
                            N.exc_count + (size_t)parity * N.exc_tiles, N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots,
                            N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles, N.exc_tiles_x, N.exc_tiles_y,
-                           (uint32_t)std::max<uint64_t>(64, n >> 11));      // more stragglers than 0.05 % of the particles: sort
+                           (uint32_t)std::max<uint64_t>(64, n >> 11),       // more stragglers than 0.05 % of the particles: sort
+                           hg);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
@@ -2228,11 +2346,27 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         g.need = N.tile_ctl + kCtlNeedSort + parity;
         g.fresh = N.tile_ctl + kCtlFresh + parity;
         g.sorts = N.tile_ctl + kCtlSorts;
-        if (gated) { g.key_copy = N.sorted_key; g.table_reset = (uint4 *)N.block_table; g.table_pairs = pairs; }
+        if (gated) {
+            g.key_copy = N.sorted_key; g.table_reset = (uint4 *)N.block_table; g.table_pairs = pairs;
+            g.count_now = hg.owned; g.sorted_count = N.tile_ctl + kCtlSortedCount;
+        }
         GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv, true,
                               N.block_table, N.table_entries, hist_now, &g));
     }
     (void)sk;
+    N.gsorted_ids_now = nullptr;
+    if (kept_sharded && g_bound > 0) {
+        // the ghosts' own grouping: (block key, particle index) pairs written by the hash, sorted every step; the last
+        // pass fills the ghosts' block table
+        Scope s(c, "shard/ghost-sort");
+        uint32_t *gk = nullptr, *gv = nullptr;
+        OnesweepGate gg;                                               // (not gated; its own tile tickets)
+        gg.ticket_base = 8;
+        GPE_TRY(onesweep_sort(c, N.gkeys, N.gids, N.gkeys_b, N.gids_b, g_bound, N.passes, true, false, &gk, &gv, true,
+                              N.gtable, N.table_entries, hg.ghist_now, &gg));
+        (void)gk;
+        N.gsorted_ids_now = gv;
+    }
     N.sort_state_valid = gated;           // (the passes of this call ran, or the kept state was and stays valid)
     N.sorted_n = n;
     N.fresh_word = N.tile_ctl + kCtlFresh + parity;
@@ -2311,6 +2445,25 @@ gpe_status native_configure(gpe_ctx *c)
         N.sorted_key = nullptr;
         GPE_HIP(c, hipMalloc((void **)&N.sorted_key, (c->cap + 16) * sizeof(uint32_t)));
         N.cap = c->cap;
+        N.gcap = 0;                                                    // (the ghost buffers follow below)
+    }
+    if (c->shard.on && (N.gcap < c->cap || N.gtable_cap < N.table_entries)) {
+        // sharded runs: the ghosts' sort buffers and block table
+        uint32_t **gb[4] = {&N.gkeys, &N.gids, &N.gkeys_b, &N.gids_b};
+        for (uint32_t **b : gb) {
+            if (*b) GPE_HIP(c, hipFree(*b));
+            *b = nullptr;
+            GPE_HIP(c, hipMalloc((void **)b, (c->cap + 16) * sizeof(uint32_t)));
+        }
+        N.gcap = c->cap;
+        if (N.gtable) GPE_HIP(c, hipFree(N.gtable));
+        N.gtable = nullptr;
+        GPE_HIP(c, hipMalloc((void **)&N.gtable, ((size_t)N.table_entries + 2) * sizeof(uint2)));
+        N.gtable_cap = N.table_entries;
+        if (!N.ghist) {
+            GPE_HIP(c, hipMalloc((void **)&N.ghist, 2 * (size_t)kHistCopies * 4 * 256 * sizeof(uint32_t)));
+            GPE_HIP(c, hipMemsetAsync(N.ghist, 0, 2 * (size_t)kHistCopies * 4 * 256 * sizeof(uint32_t), c->stream));
+        }
     }
     const uint64_t tiles = (uint64_t)((N.gx + kTileMain - 1) / kTileMain) * ((N.gy + kTileMain - 1) / kTileMain);
     {
@@ -2342,8 +2495,8 @@ gpe_status native_configure(gpe_ctx *c)
         GPE_TRY(arena_reserve(c, std::max<uint64_t>(want, N.arena_cap)));
     }
     if (!N.tile_ctl) {
-        GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, 64));
-        GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, 64, c->stream));
+        GPE_HIP(c, hipMalloc((void **)&N.tile_ctl, kCtlWords * sizeof(uint32_t)));
+        GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, kCtlWords * sizeof(uint32_t), c->stream));
     }
     if (!N.host_stat) GPE_HIP(c, hipHostMalloc((void **)&N.host_stat, 64, hipHostMallocDefault));
     memset(N.host_stat, 0, 64);
@@ -2491,6 +2644,8 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.sorted_ids = sorted_ids;
     A.codes = N.codes;
     A.fresh = N.fresh_word;
+    A.gtable = N.gsorted_ids_now ? N.gtable : nullptr;
+    A.gsorted_ids = N.gsorted_ids_now;
     A.exc_count = N.exc_count_now;
     A.exc_entry = N.exc_entry_now;
     A.exc_tiles_x = N.exc_tiles_x;
@@ -2558,7 +2713,9 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
         const uint32_t grid = ((total + 7u) / 8u) * 8u;
-        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0;
+        // (order-key windows carry four more bytes per particle: in the direct form that leaves 728 slots, 1.27 x the
+        // mean tile's particles, and too many tiles run over; the counting-sort form holds 1024)
+        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || A.order_keys != nullptr;
         if (legacy) {
             if (A.order_keys)
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
@@ -2570,15 +2727,9 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
             W.tile_x0 = cx0 / 64;
             W.tiles_x = cx1 / 64 - W.tile_x0 + 1;
             const uint32_t wgrid = (((uint32_t)W.tiles_x * (uint32_t)W.tiles_y + 7u) / 8u) * 8u;
-            if (A.order_keys)
-                hipLaunchKernelGGL((k_collide_direct<64, GPE_CAP_WIDE_ORD, true, 1024>), dim3(wgrid), dim3(1024), 0, c->stream, W);
-            else
-                hipLaunchKernelGGL((k_collide_direct<64, GPE_CAP_WIDE, false, 1024>), dim3(wgrid), dim3(1024), 0, c->stream, W);
+            hipLaunchKernelGGL((k_collide_direct<64, GPE_CAP_WIDE, false, 1024>), dim3(wgrid), dim3(1024), 0, c->stream, W);
         } else {
-            if (A.order_keys)
-                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
-            else
-                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
+            hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         }
         GPE_HIP(c, hipGetLastError());
     }

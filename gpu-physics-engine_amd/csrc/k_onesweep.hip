@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
 #ifdef GPE_OS_STAMPS
     long long _t_prev = clock64();
 #endif
-    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[pass], 1u);     // ticket: tiles start in ticket order
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[G.ticket_base + pass], 1u);     // ticket: tiles start in ticket order
     for (int i = threadIdx.x; i < kOsWaves * 256; i += kOsBlock) { (&s_whist[0][0])[i] = 0; (&s_match[0][0])[i] = 0ull; }
     __syncthreads();
     const uint32_t tile = s_tile;
@@ -198,6 +198,9 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
         }
         for (uint64_t i = (uint64_t)tile * kOsBlock + threadIdx.x; i < G.table_pairs; i += (uint64_t)gridDim.x * kOsBlock)
             G.table_reset[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);   // (first, one past last) = (max, 0): empty
+        // how many particles this grouping covers: indices from there on are not in it (sharded runs: the owned count
+        // lives on the device and moves; ghosts and arrivals behind it reach the tiles by other routes)
+        if (tile == 0 && threadIdx.x == 0) *G.sorted_count = G.count_now ? *G.count_now : (uint32_t)n;
     }
     if (G.fresh && tile == 0 && threadIdx.x == 0) {                  // last pass: the table is of this step
         *G.fresh = 1u;
@@ -423,10 +426,11 @@ gpe_status onesweep_reserve(gpe_ctx *c, uint64_t n)
         // kHistCopies histograms (the fused hash kernel spreads its flush atomics over them; the generic
         // path uses copy 0), the digit bases, the control words
         // (two sets of copies: the native step alternates between them)
-        const size_t words = 2 * (size_t)kHistCopies * 4 * 256 + 4 * 256 + 64;
+        const size_t words = 2 * (size_t)kHistCopies * 4 * 256 + 4 * 256 + 64 + 4 * 256;
         GPE_HIP(c, hipMalloc((void **)&ws.hist4, words * sizeof(uint32_t)));
         ws.bases4 = ws.hist4 + 2 * (size_t)kHistCopies * 4 * 256;
         ws.ctl = ws.bases4 + 4 * 256;
+        ws.hist_plain = ws.ctl + 64;     // the histograms of sorts that bring none (the native step's sets stay untouched)
         GPE_HIP(c, hipMemsetAsync(ws.hist4, 0, words * sizeof(uint32_t), c->stream));
     }
     return GPE_OK;
@@ -442,7 +446,7 @@ void onesweep_release(gpe_ctx *c)
 
 gpe_status onesweep_zero_hist(gpe_ctx *c)
 {
-    GPE_HIP(c, hipMemsetAsync(c->os_ws.hist4, 0, 4 * 256 * sizeof(uint32_t), c->stream));
+    GPE_HIP(c, hipMemsetAsync(c->os_ws.hist_plain, 0, 4 * 256 * sizeof(uint32_t), c->stream));
     return GPE_OK;
 }
 
@@ -465,16 +469,16 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
     OnesweepWorkspace &ws = c->os_ws;
     const uint64_t tiles = os_tiles(n);
     if (!hist_ready) {
-        ws.hist_clean = false;
         Scope s(c, "sort/hist");
         GPE_TRY(onesweep_zero_hist(c));
         hipLaunchKernelGGL(k_os_hist4, dim3(stream_grid(n, kStreamBlock)), dim3(kStreamBlock), 0, c->stream, keys, n,
-                           ws.hist4);
+                           ws.hist_plain);
         GPE_HIP(c, hipGetLastError());
     }
     if (!(hist_ready && bases_ready)) {
         Scope s(c, "sort/prepare");
-        hipLaunchKernelGGL(k_os_prepare, dim3(1), dim3(256), 0, c->stream, ws.hist4, ws.bases4, ws.ctl);
+        hipLaunchKernelGGL(k_os_prepare, dim3(1), dim3(256), 0, c->stream, hist_ready ? ws.hist4 : ws.hist_plain, ws.bases4,
+                           ws.ctl);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *ka = keys, *va = vals, *kb = keys_b, *vb = vals_b;
@@ -493,7 +497,11 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
         OnesweepGate g;                                            // (all NULL: an ordinary sort)
         if (gate) {
             g.need = gate->need;
-            if (p == 0) { g.key_copy = gate->key_copy; g.table_reset = gate->table_reset; g.table_pairs = gate->table_pairs; }
+            g.ticket_base = gate->ticket_base;
+            if (p == 0) {
+                g.key_copy = gate->key_copy; g.table_reset = gate->table_reset; g.table_pairs = gate->table_pairs;
+                g.count_now = gate->count_now; g.sorted_count = gate->sorted_count;
+            }
             if (last) { g.fresh = gate->fresh; g.sorts = gate->sorts; }
         }
         hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb, vb, n,

@@ -441,6 +441,7 @@ gpe_status gpe_shard_begin(gpe_ctx *c)
     S.begin_epoch = epoch;
     S.active = true;
     S.steps = 0;
+    c->native.sort_state_valid = false;       // the caller has just re-sorted / re-dealt the particles: a new grouping
     return launch_pack(c, true);
 }
 

@@ -197,11 +197,11 @@ class _DevArray:
 class GpeEngine:
     """One rank's particles inside a gpe context (native mode, order keys on)."""
 
-    def __init__(self, pos, rad, gid, world, gravity=(0.0, 0.0), device=0, capacity=None, profiling=False):
+    def __init__(self, pos, rad, gid, world, gravity=(0.0, 0.0), device=0, capacity=None, profiling=False, flags=0):
         from .engine import Context
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self.ctx = Context(world=world, gravity=gravity, mode=L.MODE_NATIVE, device=device, profiling=profiling)
+        self.ctx = Context(world=world, gravity=gravity, mode=L.MODE_NATIVE, device=device, profiling=profiling, flags=flags)
         # The context runs on a stream torch owns (torch never destroys its pool streams): torch's caching allocators
         # and ProcessGroupNCCL remember the stream of every buffer they handle past the context's lifetime, so the
         # stream must outlive the context -- lend it one instead of borrowing the library's (gpe_set_stream).
@@ -281,6 +281,16 @@ class GpeEngine:
         keys = self._view(L.HOME_CELL_IDS, (n,), "<i4").long() & 0xFFFFFFFF
         perm = self._view(L.PARTICLE_IDS, (n,), "<i4").long() & 0xFFFFFFFF
         return keys, perm
+
+    def argsort_u32(self, keys):
+        """Permutation that sorts `keys` (a device int32 tensor read as unsigned) ascending, stable: the library's own
+        radix sort (gpe_sort_pairs_u32) on the engine's stream.  (torch.argsort loads its sort kernels on first use --
+        seconds, and minutes when several ranks on one box do it at once.)"""
+        n = int(keys.numel())
+        k = keys.contiguous().clone()
+        v = torch.arange(n, dtype=torch.int32, device=keys.device)
+        self.ctx.call("gpe_sort_pairs_u32", C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), n)
+        return v.long()
 
     def set_active_cells(self, box):
         self.ctx.call("gpe_set_active_cells", *[int(v) for v in box])
@@ -778,7 +788,7 @@ class ShardedState:
             n = self.n_owned
             e.set_counts(n, n)
             a = e.arrays()
-            order = torch.argsort(a["gid"][:n].long())                    # ties of the key sort = old index order
+            order = e.argsort_u32(a["gid"][:n])                           # ties of the key sort = old index order
             for name in ("pos", "prev", "radius", "gid"):
                 a[name][:n] = a[name][:n][order]
             e.n_owned = n

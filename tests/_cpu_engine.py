@@ -81,6 +81,9 @@ class OracleEngine:
             self.a[k][:n] = self.a[k][:n][torch.from_numpy(perm)]
         return torch.from_numpy(keys[perm].astype(np.int64)), torch.from_numpy(perm)
 
+    def argsort_u32(self, keys):
+        return torch.from_numpy(np.argsort(keys.numpy().astype(np.int64) & 0xFFFFFFFF, kind="stable"))
+
     def set_active_cells(self, box): pass
     def refresh(self): pass
     def sync(self): pass
