@@ -524,14 +524,16 @@ def run_soak(gpe, torch, n, mode, device, total=3000, window=100, marks=(250, 50
         st.ctx.sync()
         el = time.perf_counter() - t0
         out.append({"around_step": m, "steps": window, "ms_per_step": round(el / window * 1e3, 3),
-                    "steps_per_sec": round(window / el, 2)})
+                    "steps_per_sec": round(window / el, 2), "native_sorts_so_far": st.ctx.pipeline_info()["native_sorts"]})
         log("soak: around step %d: %.3f ms/step" % (m, el / window * 1e3))
     advance(total - done)
     st.ctx.sync()
+    pipe = st.ctx.pipeline_info()
     p = st.positions()
     assert np.isfinite(p).all(), "non-finite positions after the soak"
     st.close()
-    return {"workload": "%d particles, gravity on, %d steps, re-sort every %d" % (n, total, RESORT_EVERY), "marks": out}
+    return {"workload": "%d particles, gravity on, %d steps, re-sort every %d" % (n, total, RESORT_EVERY), "marks": out,
+            "pipeline": pipe}
 
 
 def main():

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
         if (nv - n_own > G.g_bound && threadIdx.x == 0) atomicOr(&tile_ctl[kCtlError], kErrBoundExceeded);
     }
     bool oob = false, drifted = false;
+    bool sort_known = sorted_key == nullptr;                           // (wave-uniform) the radix passes will run this step
     for (uint64_t r0 = 0; r0 < rounds; r0 += kHashBatch) {
         float2 p[kHashBatch];
         float rad[kHashBatch];
@@ -357,14 +358,27 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 // Stragglers are meant to be the few fast particles of a hot cloud.  When the whole cloud moves (free
                 // fall) a large share of the particles runs out of reach within a step or two: handing millions of
                 // them over, at up to four atomics each, costs more than the sort that makes them ordinary again.
+                // Once the sort is known to run, handing stragglers over is wasted work (the tiles then ignore the lists):
+                // a crushed scene makes a third of the particles stragglers, and their atomics -- one per wave on the
+                // counter, up to four per particle on the lists -- took longer than the tiles (100 M soak, step 1000:
+                // 22 ms/step with them, 16 without).
                 const uint64_t ms = __ballot(straggler);
-                if (ms != 0) {                                           // (wave-uniform)
-                    uint32_t before = 0;
-                    if (lane_id() == (int)__builtin_ctzll(ms))
-                        before = atomicAdd(&tile_ctl[parity ? kCtlStragglers1 : kCtlStragglers0], (uint32_t)__popcll(ms));
-                    if (before + (uint32_t)__popcll(ms) > straggler_limit) drifted = true;    // (the adding lane only: enough)
+                bool route = false;
+                if (ms != 0 && !sort_known) {                            // (wave-uniform)
+                    sort_known = __hip_atomic_load(&tile_ctl[kCtlNeedSort + parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                    if (!sort_known) {
+                        const int leader = (int)__builtin_ctzll(ms);
+                        uint32_t before = 0;
+                        if (lane_id() == leader)
+                            before = atomicAdd(&tile_ctl[parity ? kCtlStragglers1 : kCtlStragglers0], (uint32_t)__popcll(ms));
+                        before = (uint32_t)__builtin_amdgcn_readlane((int)before, leader);
+                        if (before + (uint32_t)__popcll(ms) > straggler_limit) {
+                            sort_known = true;
+                            if (lane_id() == leader) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
+                        } else route = true;
+                    }
                 }
-                if (straggler) {
+                if (straggler && route) {
                     // every 32x32 tile whose window [32 tx - 5, 32 tx + 35] x [32 ty - 3, 32 ty + 33] holds the cell
                     // (sub-tiles of the over-capacity launch read their parent's list: their windows lie inside its)
                     const int tx0 = max(0, (cx - (kConeRight + 1)) >> 5), tx1 = min(exc_tiles_x - 1, (cx + kConeLeft + 1) >> 5);
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                             const uint32_t t = (uint32_t)(ty * exc_tiles_x + tx);
                             const uint32_t slot = atomicAdd(&exc_count[t], 1u);
                             if (slot < kExcSlots) exc_entry[(uint64_t)t * kExcSlots + slot] = make_uint2((uint32_t)idx[u], (uint32_t)cx | ((uint32_t)cy << 16));
-                            else drifted = true;                          // a list ran over: sort
+                            else { drifted = true; atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u); }   // a list ran over: sort (and tell the others)
                         }
                 }
             }
@@ -1142,6 +1156,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     const int ox = tx * T - HX, oy = ty * T - HY;                      // origin of the cell window
     const int box = (tx * T - kHalo) >> 3, boy = (ty * T - kHalo) >> 3;   // first looked-up block
     GPE_STAMP_BEGIN();
+    // (issued here, consumed behind P0: a crowded scene runs tens of thousands of short-lived tiles and sub-tiles, and a
+    // global round trip exposed in each of them cost the dense launch a quarter of its time again: 5.95 -> 7.5 ms at
+    // step 1000 of the 100 M soak)
+    const uint32_t fresh_word = *A.fresh;
+    const uint32_t owned_word = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
+    uint32_t exc_word = 0;
+    if (A.exc_count) exc_word = A.exc_count[(uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5)];
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
     S.cell_clear(tid);
@@ -1196,21 +1217,18 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     }
     __syncthreads();
     const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);   // the same in every lane: keep it scalar
-    // Nothing of its own to write: no particle in the tile's own blocks AND in the ring around them (a particle may have
-    // drifted up to kDrift* cells out of the block the table lists it in, so the own blocks alone do not tell).
-    if (P == 0) return true;
     // (relative cell -> cell inside the block when the table is of this step: the value mod 8; else unchanged)
-    const bool stale = __builtin_amdgcn_readfirstlane((int)*A.fresh) == 0;
-    const uint32_t n_owned_now = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
+    const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
+    const uint32_t n_owned_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)owned_word);
     const int rel_mask = stale ? -1 : 7;
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;       // (listed under a block it is out of reach of: skipped)
     // stragglers handed to this tile's 32x32 parent by the hash kernel (P1 files them behind the looked-up particles)
-    uint32_t n_exc = 0;
-    if (stale && A.exc_count) {
-        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
-        n_exc = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.exc_count[pt]), kExcSlots);
-    }
+    const uint32_t n_exc = stale ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)exc_word), kExcSlots) : 0u;
+    // Nothing of its own to write?  With the table of this step: no particle in the tile's own blocks.  With a kept
+    // table a particle may have drifted up to kDrift* cells out of the block that lists it, so only an empty lookup
+    // region (own blocks + the ring around them) AND an empty straggler list tell -- a straggler that flew into empty
+    // space exists for its tile through the list alone (test_stragglers_flying_into_empty_space_are_not_lost).
+    if (stale ? (P == 0 && n_exc == 0) : S.misc[1] == 0) return true;
     if constexpr (L::kGlobal) {
         // take a slice of the global spill arena for this tile's particle arrays
         if (tid == 0) {
@@ -1441,8 +1459,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // The tile's own particles and, when K12 is fused into the write-back, their previous positions: fetched
     // here so that the global round trip runs under the colour passes instead of at the end of the tile.
     // (a scalar, so that comparing against it waits for no load: the count of a sharded run is read here, once)
-    const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
+    const uint32_t n_owned = n_owned_now;
     constexpr int QOWN = (L::kSlots + kNatThreads - 1) / kNatThreads;  // ceil(kept capacity / threads)
     uint32_t own_id[QOWN];
     float2 own_prev[QOWN];
@@ -1806,6 +1823,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     const int ox = tx * TX - HX, oy = ty * TY - HY;                    // origin of the cell window
     const int box = (tx * TX - kHalo) >> 3, boy = (ty * TY - kHalo) >> 3;   // first looked-up block
     GPE_STAMP_BEGIN();
+    const uint32_t fresh_word = *A.fresh;                              // (issued here, consumed behind P0: see process_tile)
+    const uint32_t owned_word = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
 
     // ---- P0: clear the counters, look the region's blocks up, slot -> block map (as process_tile) ------------------
     for (int i = tid; i < (NZ + 1) / 2; i += NT) S.cntw[i] = 0;
@@ -1837,6 +1856,15 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (lane == 0) { S.boff[VB] = carry; S.misc[0] = carry; S.misc[2] = 0; S.misc[3] = 0; S.misc[4] = 0; }
+        {                                                              // particles in the tile's own blocks (misc[1])
+            static_assert(NBLK <= 64, "one lane per block");
+            const int bi = lane % NBX, bj = lane / NBX;
+            const bool own_blk = lane < NBLK && bi >= 1 && bi < NBX - 1 && bj >= 1 && bj < NBY - 1;
+            uint32_t v = 0;
+            if (own_blk) v = S.bcnt[lane] + (ORD ? S.bcnt[lane + NBLK] : 0u);
+            const uint32_t own = wave_sum(v);                          // (all 64 lanes of wave 0 take part)
+            if (lane == 0) S.misc[1] = own;
+        }
     } else if (tid < 64 + (NBX - 2) * (NBY - 2)) {
         const int wi = (tid - 64) % (NBX - 2), wj = (tid - 64) / (NBX - 2);
         uint32_t w = 0;
@@ -1848,10 +1876,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     }
     __syncthreads();
     const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);
-    if (P == 0) return true;
-    const bool stale = __builtin_amdgcn_readfirstlane((int)*A.fresh) == 0;
-    const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull)));
+    const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
+    const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane((int)owned_word);
     const int rel_mask = stale ? -1 : 7;
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
     // stragglers: the lists of the 32x32 tiles this tile covers (one, or two side by side for a 64-cell-wide tile)
@@ -1864,6 +1890,14 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         const int ptx = tx * NPAR + pi;
         if (stale && A.exc_count && ptx < A.exc_tiles_x)
             n_exc[pi] = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.exc_count[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)ptx]), kExcSlots);
+    }
+    {
+        // nothing of its own to write?  (see process_tile: own blocks with the table of this step; the whole lookup
+        // region and the straggler lists with a kept table)
+        uint32_t any_exc = 0;
+#pragma unroll
+        for (int pi = 0; pi < NPAR; ++pi) any_exc |= n_exc[pi];
+        if (stale ? (P == 0 && any_exc == 0) : S.misc[1] == 0) return true;
     }
     if (P > (uint32_t)L::RAWCAP) return false;                         // more looked-up particles than slots
     {
@@ -2389,6 +2423,7 @@ gpe_status native_configure(gpe_ctx *c)
     N.steps_since_check = 0;
     N.sort_state_valid = false;          // particles, box or keys changed: the kept grouping is of something else
     N.quiet_steps = 0;
+    N.crowded = false;
     N.always_sort = (c->cfg.flags & GPE_FLAG_SORT_EVERY_STEP) != 0;
     N.reason = GPE_REASON_NO_PARTICLES;
     if (c->n == 0 || !(c->cell_size > 0.0f)) return GPE_OK;
@@ -2713,9 +2748,27 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
         const uint32_t grid = ((total + 7u) / 8u) * 8u;
+        // Which form of the tile?  The direct-slot form is the faster one while tiles fit it; it holds 928 particles and
+        // hands a tile on when its cells crowd (more than 96 memberships beyond a cell's sixth, a cell of more than 64).
+        // In a compressed scene (the 100 M cloud after a few hundred steps of gravity) most tiles would take that
+        // detour through the over-capacity launch, while the counting-sort form holds 1192 particles and resolves
+        // crowded cells in place.  So the choice follows the tiles' own report (lagged by the steps in flight; either
+        // form is exact): counting-sort tiles once more than 2 % of the direct-slot tiles ran over; back to direct
+        // slots when no 24x24-cell window has held more than 512 particles (2.3 x the mean of the benchmark density; a
+        // direct-slot window overflows around 350) and no tile has run over for 64 steps.
         // (order-key windows carry four more bytes per particle: in the direct form that leaves 728 slots, 1.27 x the
         // mean tile's particles, and too many tiles run over; the counting-sort form holds 1024)
-        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || A.order_keys != nullptr;
+        if (N.host_stat) {
+            const uint32_t over = N.host_stat[kStatOverflow];
+            if (!N.crowded) {
+                if (over > total / 50u + 4u) { N.crowded = true; N.calm_steps = 0; }
+            } else {
+                N.calm_steps = (over == 0 && N.host_stat[kStatWindowMax] == 0) ? N.calm_steps + 1 : 0;
+                if (N.calm_steps >= 64) N.crowded = false;
+            }
+        }
+        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || A.order_keys != nullptr ||
+                            (N.crowded && (c->cfg.flags & GPE_FLAG_WIDE_TILES) == 0);
         if (legacy) {
             if (A.order_keys)
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);

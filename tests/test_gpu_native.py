@@ -626,3 +626,27 @@ def test_other_tile_forms_give_the_same_bits(gpe, oracle, flag):
     assert np.array_equal(a.previous_positions(), b.previous_positions())
     a.ctx.sync(); b.ctx.sync()
     a.close(); b.close(); sim.close()
+
+
+def test_stragglers_flying_into_empty_space_are_not_lost(gpe, oracle):
+    """A few very fast particles shot out of a compact cloud into an otherwise empty world: their tiles look nothing up
+    (no block of the kept table lies near them), so they exist for those tiles only through the straggler lists.  Exact
+    against the oracle at every step, and the cloud itself does not force a sort every step."""
+    rng = np.random.default_rng(77)
+    world = (700.0, 500.0)
+    n = 30_000
+    pos = (np.array([60.0, 60.0], np.float32) + rng.random((n, 2), dtype=np.float32) * np.float32(300.0)).astype(np.float32)
+    rad = np.full(n, 0.5, np.float32)
+    prev = pos.copy()
+    fast = rng.choice(n, 40, replace=False)
+    ang = rng.random(40) * 2 * np.pi
+    speed = 6.0 + 9.0 * rng.random(40)                                   # 5-14 cells per step, in every direction
+    prev[fast] = (pos[fast] - np.stack([np.cos(ang) * speed, np.sin(ang) * speed], 1)).astype(np.float32)
+    st = gpe.State(pos, rad, world=world, prev=prev)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5), prev=prev)
+    for s in range(45):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        _assert_positions(st.positions(), sim.pos, "fast particles in empty space, step %d" % s)
+    info = st.ctx.pipeline_info()
+    assert info["native_steps"] == 45 and info["native_sorts"] < 30, info
+    st.close(); sim.close()
