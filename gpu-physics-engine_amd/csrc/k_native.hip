@@ -90,12 +90,17 @@ constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every
 constexpr int kCtlError = 8;                   // sticky
 // Two words each, indexed by the parity of the step (native_prepare_step counts them): a step's hash kernel clears
 // the NEXT step's word while its own is being set, so no workgroup of a launch races with another's reset.
-constexpr int kCtlNeedSort = 10;               // [parity] the hash found a particle outside the drift its code can express
-constexpr int kCtlFresh = 12;                  // [parity] the radix passes ran: the block table describes THIS step's positions
+// (The words the tiles only READ -- fresh, sorted count -- live in a 128-byte line of their own, the L2's granule: the
+// first line holds the words every tile and every work item of the over-capacity launch hammers with atomics (overflow
+// count, work ticket, window maximum, arena), and a load from a line under atomic fire queues behind them: with
+// `fresh` next to the ticket P0 of a tile took 11.5 k instead of 5.9 k cycles and the over-capacity launch 6.3 instead
+// of 4.1 ms at step 1000 of the 100 M soak.)
+constexpr int kCtlNeedSort = 34;               // [parity] the hash found a particle outside the drift its code can express
+constexpr int kCtlFresh = 36;                  // [parity] the radix passes ran: the block table describes THIS step's positions
 constexpr int kCtlSorts = kNativeCtlSorts;     // steps whose radix passes ran (running count, gpe_get_pipeline_info)
 constexpr int kCtlStragglers0 = 9, kCtlStragglers1 = 15;   // [parity] stragglers found by the step's hash so far
-constexpr int kCtlSortedCount = 16;            // particles the kept grouping covers (written by the first radix pass)
-constexpr int kCtlWords = 32;                  // tile_ctl is this long
+constexpr int kCtlSortedCount = 32;            // particles the kept grouping covers (written by the first radix pass)
+constexpr int kCtlWords = 64;                  // tile_ctl is this long (two 128-byte lines)
 // How far a particle may have left the 8x8-cell block it was sorted into (cells beyond the block's extent, per
 // direction) and still be found by every tile that needs it.  A tile looks up the blocks of tile +- 8 cells but keeps
 // only the window [x0-5, x1+4] x [y0-3, y1+2] (kCone* + 1): a kept particle that moved right by dr cells comes from a
