@@ -283,6 +283,9 @@ struct NativeState {
                                      // first pass); the sorted ids and the block table describe that grouping
     bool sort_state_valid = false;   // sorted_key / sorted ids / block table belong to the current particle set and box
     uint64_t sorted_n = 0;           // ... of this many particles
+    uint32_t sort_hold = 0;          // steps left that sort unconditionally (the scene sorted on most steps anyway)
+    uint32_t watch_steps = 0, watch_sorts = 0;   // the passes' counter over the current 64-step window
+    bool watch_valid = false;
     uint32_t calm_steps = 0;         // steps without an over-capacity tile or a crowded window while `crowded`
     bool crowded = false;            // many tiles run over the direct-slot form: the dense launch uses the counting-sort form
     uint32_t quiet_steps = 0;        // native steps since the tiles last reported an over-capacity 32x32 tile (lagged)

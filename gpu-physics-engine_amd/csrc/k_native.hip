@@ -123,6 +123,7 @@ constexpr int kStatArena = 1;                  // spill-arena slots handed out b
 constexpr int kStatProbe = 2;                  // window population measured by the last asynchronous probe + 1 (0: none yet)
 constexpr int kStatOverflow = 3;               // 32x32 tiles over capacity in the last native step
 constexpr int kStatSubTiles = 4, kStatSpills = 5;   // quarters redone as 8x8 tiles / 8x8 tiles through the arena (diagnostics)
+constexpr int kStatSorts = 6;                  // running count of steps whose radix passes ran (tile_ctl[kCtlSorts]), lagged
 constexpr uint64_t kArenaBytesPerSlot = 37;     // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 constexpr uint64_t kArenaMaxSlots = 1ull << 30; // the arena's slot numbers are 32 bit; 40 GB of the 288 GB
 // tile sizes (cells) and LDS capacities (particles staged per region)
@@ -211,6 +212,8 @@ struct HashGhosts {
 constexpr int kHashBlock = 1024;
 constexpr int kHashBatch = 2;                  // positions loaded per lane before any of them is ranked
 constexpr int kHashGridMax = 2048;
+// GHOSTS: a sharded run with its counts on the device (HashGhosts); the ordinary instantiation carries none of that code.
+template <bool GHOSTS>
 __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__restrict__ pos,
                                                             const float *__restrict__ radius, uint64_t n,
                                                             const uint32_t *__restrict__ n_valid_ptr,
@@ -237,9 +240,11 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     // parity]; the radix passes that follow look at the word and return at once when it is 0.
     // sorted_key == NULL: always sort (first step, sharded runs, one-pass sorts).
     __shared__ uint32_t s_hist[4 * 256];
-    __shared__ uint32_t s_ghist[4 * 256];                              // (the ghosts' keys, sharded runs)
+    __shared__ uint32_t s_ghist[GHOSTS ? 4 * 256 : 1];                 // (the ghosts' keys, sharded runs)
+    __shared__ uint32_t s_sort_known;                                  // a wave of this workgroup has seen the straggler limit passed
     s_hist[threadIdx.x] = 0;
-    s_ghist[threadIdx.x] = 0;
+    if (GHOSTS) s_ghist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_sort_known = 0u;
     // What a step accumulates into is reset here instead of by a launch of its own (a launch costs ~6 us, 5 % of
     // the step at 1 M particles): the block table (filled two kernels later), and -- workgroup 0 -- the per-step
     // control words, after handing the previous step's window statistic to the host (pinned memory), the radix
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     // this step's set is read by the radix passes that follow, nobody touches the other one meanwhile).
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         table2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);      // (first, one past last) = (max, 0): empty
+    if (GHOSTS)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.gtable_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         G.gtable2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);   // the ghosts' block table: rebuilt every step
     if (exc_count_next) {                                              // the next step's straggler lists
@@ -261,12 +267,13 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
             if (threadIdx.x == kCtlOverflow1) host_stat[kStatOverflow] = tile_ctl[kCtlOverflow1];
             if (threadIdx.x == kCtlSubTiles) host_stat[kStatSubTiles] = tile_ctl[kCtlSubTiles];
             if (threadIdx.x == kCtlSpills) host_stat[kStatSpills] = tile_ctl[kCtlSpills];
+            if (threadIdx.x == 7) host_stat[kStatSorts] = tile_ctl[kCtlSorts];
         }
         tile_ctl[threadIdx.x] = 0;
     }
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kHashBlock) hist_next[i] = 0;
-        if (G.ghist_next)
+        if (GHOSTS && G.ghist_next)
             for (int i = threadIdx.x; i < kHistCopies * 4 * 256; i += kHashBlock) G.ghist_next[i] = 0;
         if (threadIdx.x < 16) os_ctl[threadIdx.x] = 0;                 // tile tickets (owned [0..3], ghosts [8..11]) + error word [4]
         if (threadIdx.x == 0) {                                        // the next step's words; this step's if it must sort
@@ -288,9 +295,9 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     }
     // owned particles [0, n_own), ghosts [n_own, nv); indices from sorted_cnt on are not in the kept grouping
     uint64_t n_own = nv;
-    if (G.owned) n_own = min((uint64_t)*G.owned, nv);
+    if (GHOSTS && G.owned) n_own = min((uint64_t)*G.owned, nv);
     const uint64_t sorted_cnt = (sorted_key && G.sorted_count) ? (uint64_t)*G.sorted_count : ~0ull;
-    if (G.gkeys) {
+    if (GHOSTS && G.gkeys) {
         // ghost slots behind the last one the particle loop below reaches: padding (sorts behind every block)
         const uint64_t first = n - n_own;
         for (uint64_t j = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G.g_bound; j += (uint64_t)gridDim.x * blockDim.x) {
@@ -320,9 +327,9 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
             uint32_t key = pad_key;
             if (valid && idx[u] >= nv) {
                 keys[idx[u]] = pad_key; codes[idx[u]] = 0u;
-                if (G.gkeys && idx[u] - n_own < G.g_bound) { G.gkeys[idx[u] - n_own] = pad_key; G.gids[idx[u] - n_own] = 0u; }
+                if (GHOSTS && G.gkeys && idx[u] - n_own < G.g_bound) { G.gkeys[idx[u] - n_own] = pad_key; G.gids[idx[u] - n_own] = 0u; }
             }
-            const bool ghost = idx[u] >= n_own;
+            const bool ghost = GHOSTS && idx[u] >= n_own;
             uint32_t gkey = 0;
             bool gvalid = false;
             if (idx[u] < nv) {
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                                  (lby < 0) | (lby >= blocks_y);
                 oob |= out;
                 key = out ? 0u : (uint32_t)(lby * blocks_x + lbx);
-                if (ghost && G.gkeys) {
+                if (GHOSTS && ghost && G.gkeys) {
                     // a ghost: grouped by the ghosts' own sort; in the owned particles' sort it is padding
                     const uint64_t j = idx[u] - n_own;
                     if (j < G.g_bound) { G.gkeys[j] = key; G.gids[j] = (uint32_t)idx[u]; gkey = key; gvalid = true; }
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 // multiply: exact for okey * blocks_x < 2^40 (keys < 2^27, blocks_x <= 2^13).
                 int32_t relx = cx & 7, rely = cy & 7;
                 bool straggler = false;
-                if (sorted_key && !(ghost && G.gkeys)) {
+                if (sorted_key && !(GHOSTS && ghost && G.gkeys)) {
                     const uint32_t oby = (uint32_t)(((uint64_t)okey[u] * div_magic) >> 40);
                     const uint32_t obx = okey[u] - oby * (uint32_t)blocks_x;
                     relx = cx - (int32_t)((obx + (uint32_t)bx0) << 3);
@@ -366,11 +373,12 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 // Once the sort is known to run, handing stragglers over is wasted work (the tiles then ignore the lists):
                 // a crushed scene makes a third of the particles stragglers, and their atomics -- one per wave on the
                 // counter, up to four per particle on the lists -- took longer than the tiles (100 M soak, step 1000:
-                // 22 ms/step with them, 16 without).
+                // 22 ms/step with them, 16 without).  A wave learns it from the counter itself (its own add comes back
+                // above the limit) or from its workgroup (an LDS word): no extra global round trip in calm scenes.
                 const uint64_t ms = __ballot(straggler);
                 bool route = false;
                 if (ms != 0 && !sort_known) {                            // (wave-uniform)
-                    sort_known = __hip_atomic_load(&tile_ctl[kCtlNeedSort + parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                    sort_known = wave_lds_load(&s_sort_known) != 0u;     // (another wave of the workgroup has learnt it)
                     if (!sort_known) {
                         const int leader = (int)__builtin_ctzll(ms);
                         uint32_t before = 0;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                         before = (uint32_t)__builtin_amdgcn_readlane((int)before, leader);
                         if (before + (uint32_t)__popcll(ms) > straggler_limit) {
                             sort_known = true;
-                            if (lane_id() == leader) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
+                            if (lane_id() == leader) { wave_lds_store(&s_sort_known, 1u); atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u); }
                         } else route = true;
                     }
                 }
@@ -400,14 +408,14 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q < digits) hist_add(s_hist + q * 256, (key >> (8 * q)) & 255u, valid);
-            if (G.gkeys) {                                             // (uniform)
+            if (GHOSTS && G.gkeys) {                                   // (uniform)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (q < digits) hist_add(s_ghist + q * 256, (gkey >> (8 * q)) & 255u, gvalid);
             }
         }
     }
-    if (G.gkeys && blockIdx.x == 0 && threadIdx.x < (uint32_t)digits) {
+    if (GHOSTS && G.gkeys && blockIdx.x == 0 && threadIdx.x < (uint32_t)digits) {
         // the ghost sort covers g_bound slots: those behind the ghosts hold the padding key
         const uint64_t ng = min(nv - n_own, G.g_bound);
         atomicAdd(&s_ghist[threadIdx.x * 256 + ((pad_key >> (8 * threadIdx.x)) & 255u)], (uint32_t)(G.g_bound - ng));
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
             __hip_atomic_fetch_add(
                 reinterpret_cast<unsigned long long *>(&hist4[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
                 (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (G.ghist_now) {
+        if (GHOSTS && G.ghist_now) {
             const uint32_t glo = s_ghist[threadIdx.x], ghi = s_ghist[threadIdx.x + 1];
             if (glo | ghi)
                 __hip_atomic_fetch_add(
@@ -2333,10 +2341,23 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     // their indices are stable (a hole left by a migrant is filled from the tail, an arrival is appended: both reach
     // the tiles as stragglers until the next sort), while the ghosts -- new every step -- are grouped by a small sort
     // of their own, every step, into a second block table.  Other sharded set-ups (host-side counts) always sort.
+    // A scene in which nearly every step sorts anyway (a crushed pile: a third of the particles move further than the
+    // kept table reaches, every step) gains nothing from the kept table and pays for it in the hash kernel (the old
+    // keys, the drift test: 1.2 instead of 0.6 ms at 100 M).  The passes' own counter says so (lagged): when three
+    // quarters of the last 64 steps sorted, the next 256 steps sort unconditionally; then the table gets another try.
+    if (N.host_stat && !always_sort) {
+        if (N.sort_hold > 0) --N.sort_hold;
+        if (++N.watch_steps >= 64) {
+            const uint32_t sorts = N.host_stat[kStatSorts];
+            if (N.sort_hold == 0 && N.watch_valid && sorts - N.watch_sorts >= 48) N.sort_hold = 256;
+            N.watch_sorts = sorts; N.watch_steps = 0; N.watch_valid = true;
+        }
+    }
     const bool sharded = c->shard.on || c->use_order_keys || c->has_active_box;
     const bool kept_sharded = c->shard.on && c->shard.active && c->use_order_keys && N.gkeys != nullptr && !N.always_sort;
     const bool gated = N.passes >= 2 && (!sharded || kept_sharded);
-    const bool reuse = gated && !always_sort && N.sort_state_valid && (kept_sharded || N.sorted_n == n) && !N.always_sort;
+    const bool reuse = gated && !always_sort && N.sort_state_valid && (kept_sharded || N.sorted_n == n) && !N.always_sort &&
+                       N.sort_hold == 0;
     const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;        // the table is allocated in 16-byte units
     HashGhosts hg;
     hg.sorted_count = N.tile_ctl + kCtlSortedCount;
@@ -2365,7 +2386,8 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         const int grid = (int)std::min<uint64_t>(kHashGridMax, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
         const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr;
         const uint64_t div_magic = ((1ull << 40) + (uint64_t)N.blocks_x - 1) / (uint64_t)N.blocks_x;
-        hipLaunchKernelGGL(k_native_hash, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
+        const auto hash_kernel = kept_sharded ? k_native_hash<true> : k_native_hash<false>;
+        hipLaunchKernelGGL(hash_kernel, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
                            c->cell_size, N.gx, N.gy, N.bx0, N.by0, N.blocks_x, N.blocks_y, N.table_entries, N.keys,
                            N.codes, N.passes, hist_now, hist_next, c->os_ws.ctl, N.tile_ctl,
                            (uint4 *)N.block_table, gated ? 0ull : pairs,    // gated: the first radix pass resets the table
@@ -2429,6 +2451,7 @@ gpe_status native_configure(gpe_ctx *c)
     N.sort_state_valid = false;          // particles, box or keys changed: the kept grouping is of something else
     N.quiet_steps = 0;
     N.crowded = false;
+    N.sort_hold = 0; N.watch_steps = 0; N.watch_valid = false;
     N.always_sort = (c->cfg.flags & GPE_FLAG_SORT_EVERY_STEP) != 0;
     N.reason = GPE_REASON_NO_PARTICLES;
     if (c->n == 0 || !(c->cell_size > 0.0f)) return GPE_OK;
