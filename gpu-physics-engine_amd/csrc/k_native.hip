@@ -106,17 +106,24 @@ constexpr int kCtlWords = 64;                  // tile_ctl is this long (two 128
 // only the window [x0-5, x1+4] x [y0-3, y1+2] (kCone* + 1): a kept particle that moved right by dr cells comes from a
 // block that starts at >= (x0-5) - 7 - dr, inside the lookup (>= x0-15, block-aligned: x0-8) while dr <= 3; moved left:
 // its block starts at <= x1+4+dl <= x1+8 while dl <= 4; up: >= (y0-3) - 7 - du >= y0-15 while du <= 5; down: <= y1+2+dd
-// <= y1+8 while dd <= 6.  The code keeps the cell relative to the OLD block in 4 + 4 bits: x in [-4, 10], y in [-6, 9].
-constexpr int kDriftLeft = 4, kDriftRight = 3, kDriftDown = 6, kDriftUp = 2;
+// <= y1+8 while dd <= 6.
+constexpr int kDriftLeft = 4, kDriftRight = 3, kDriftDown = 6, kDriftUp = 5;
+// The code word of a particle (k_native_hash -> tiles): its cell MOD 128 per axis (a tile's lookup region plus the drift
+// spans fewer than 128 cells, so the value names one cell of it) | the overlap mask of the 8 neighbour cells | straggler.
+constexpr uint32_t kCodeCellMask = 127u;
+constexpr int kCodeYShift = 7, kCodeOverlapShift = 14;
 // A particle beyond that reach (a straggler: in a cloud without damping a few particles are always fast) does not
 // force a sort by itself: the hash kernel hands it, with its cell, to every 32x32 tile whose cell window holds it
 // (at most four), kExcSlots per tile, and marks its code so that the tiles skip it in the old block's list.  Only a
 // tile's list running over raises kCtlNeedSort.  Two sets of lists, by step parity (reset like the control words).
 constexpr uint32_t kExcSlots = 16;
-constexpr uint32_t kCodeStraggler = 1u << 16;
+constexpr uint32_t kCodeStraggler = 1u << 22;
 static_assert(kDriftRight <= kHalo - (kConeLeft + 1) && kDriftLeft <= kHalo - (kConeRight + 1), "x drift inside the lookup slack");
 static_assert(kDriftUp <= kHalo - (kConeDown + 1) && kDriftDown <= kHalo - (kConeUp + 1), "y drift inside the lookup slack");
-static_assert(kDriftLeft + 8 + kDriftRight <= 16 && kDriftDown + 8 + kDriftUp <= 16, "relative cell fits 4 bits per axis");
+static_assert(64 + 2 * kHalo + kDriftLeft + kDriftRight < 128 && 32 + 2 * kHalo + kDriftDown + kDriftUp < 128, "a lookup region + drift names every cell mod 128 once");
+// window coordinate of the cell a code names, for a window whose first cell is o (any sign): in [0, 128)
+__device__ __forceinline__ int code_window_x(uint32_t code, int o) { return (int)((code - (uint32_t)o) & kCodeCellMask); }
+__device__ __forceinline__ int code_window_y(uint32_t code, int o) { return (int)(((code >> kCodeYShift) - (uint32_t)o) & kCodeCellMask); }
 // pinned host words the kernels report to (read by the step policy with a lag of the steps in flight)
 constexpr int kStatWindowMax = 0;              // largest 24x24-cell window population of the last native step
 constexpr int kStatArena = 1;                  // spill-arena slots handed out by the last native step
@@ -347,26 +354,25 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                     key = pad_key;
                 }
                 keys[idx[u]] = key;
-                // The particle's cell relative to the first cell of the block it was SORTED into (== its block of now
-                // when the passes run this step: then the tiles take the value mod 8).  okey / blocks_x by a 64-bit
-                // multiply: exact for okey * blocks_x < 2^40 (keys < 2^27, blocks_x <= 2^13).
-                int32_t relx = cx & 7, rely = cy & 7;
+                // The particle's cell relative to the first cell of the block it was SORTED into: is it still within the
+                // reach of the tiles that find it through that block?  okey / blocks_x by a 64-bit multiply: exact for
+                // okey * blocks_x < 2^40 (keys < 2^27, blocks_x <= 2^13).
                 bool straggler = false;
                 if (sorted_key && !(GHOSTS && ghost && G.gkeys)) {
                     const uint32_t oby = (uint32_t)(((uint64_t)okey[u] * div_magic) >> 40);
                     const uint32_t obx = okey[u] - oby * (uint32_t)blocks_x;
-                    relx = cx - (int32_t)((obx + (uint32_t)bx0) << 3);
-                    rely = cy - (int32_t)((oby + (uint32_t)by0) << 3);
+                    const int32_t relx = cx - (int32_t)((obx + (uint32_t)bx0) << 3);
+                    const int32_t rely = cy - (int32_t)((oby + (uint32_t)by0) << 3);
                     // out of reach of its old block, or not in the kept grouping at all (an arrival of a sharded run,
                     // filed behind the particles the last sort covered): handed to the tiles directly
                     straggler = !out && ((relx < -kDriftLeft) | (relx > 7 + kDriftRight) | (rely < -kDriftDown) | (rely > 7 + kDriftUp) |
                                          (idx[u] >= sorted_cnt));
                 }
-                // what the tiles need to file the particle: that relative cell and its phantom cells.
+                // what the tiles need to file the particle: its cell (mod 128) and its phantom cells.
                 // Computed once here instead of by each of the ~2.25 tiles that stage the particle.
-                // (A straggler's relative cell is still right mod 8, which is what the tiles use when the passes run.)
-                codes[idx[u]] = ((uint32_t)(relx + kDriftLeft) & 15u) | (((uint32_t)(rely + kDriftDown) & 15u) << 4) |
-                                (neighbour_overlap_mask(p[u], rad[u], cx, cy, cell_size) << 8) | (straggler ? kCodeStraggler : 0u);
+                codes[idx[u]] = ((uint32_t)cx & kCodeCellMask) | (((uint32_t)cy & kCodeCellMask) << kCodeYShift) |
+                                (neighbour_overlap_mask(p[u], rad[u], cx, cy, cell_size) << kCodeOverlapShift) |
+                                (straggler ? kCodeStraggler : 0u);
                 // Stragglers are meant to be the few fast particles of a hot cloud.  When the whole cloud moves (free
                 // fall) a large share of the particles runs out of reach within a step or two: handing millions of
                 // them over, at up to four atomics each, costs more than the sort that makes them ordinary again.
@@ -506,8 +512,7 @@ struct CollideArgs {
     const float *radius;
     float2 *pos_out;
     const uint32_t *sorted_ids;
-    const uint32_t *codes;       // per particle: cell relative to the block it was sorted into (4 + 4 bits, biased by
-                                 // kDriftLeft / kDriftDown) | neighbour overlap mask (8 bits) | kCodeStraggler
+    const uint32_t *codes;       // per particle: cell mod 128 (7 + 7 bits) | neighbour overlap mask (8 bits) | kCodeStraggler
     const uint2 *gtable;         // sharded runs: (start, end) of every block among the GHOSTS, sorted every step (else NULL)
     const uint32_t *gsorted_ids; // ... and their particle indices in that order
     const uint32_t *exc_count;   // stragglers handed to each 32x32 tile this step (NULL: none, the run always sorts)
@@ -1230,10 +1235,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     }
     __syncthreads();
     const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);   // the same in every lane: keep it scalar
-    // (relative cell -> cell inside the block when the table is of this step: the value mod 8; else unchanged)
     const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
     const uint32_t n_owned_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)owned_word);
-    const int rel_mask = stale ? -1 : 7;
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;       // (listed under a block it is out of reach of: skipped)
     // stragglers handed to this tile's 32x32 parent by the hash kernel (P1 files them behind the looked-up particles)
     const uint32_t n_exc = stale ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)exc_word), kExcSlots) : 0u;
@@ -1320,10 +1323,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
-            const uint32_t rb = ORD ? blk[q] % (uint32_t)NBLK : blk[q];
-            lxq[q] = (int)(rb % NB) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
-            lyq[q] = (int)(rb / NB) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
-            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
+            lxq[q] = code_window_x(cc[q], ox);
+            lyq[q] = code_window_y(cc[q], oy);
+            keep[q] = s < P && lxq[q] < RWX && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
             // (an order-key window: the kept table may still list indices the owned range has shrunk below -- those
             // particles are ghosts now, or gone: they come through the ghosts' table, or not at all)
             if constexpr (ORD) keep[q] = keep[q] && (A.gtable == nullptr || blk[q] >= (uint32_t)NBLK || lidq[q] < n_owned_now);
@@ -1366,7 +1368,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             const int home = (ly + 1) * PX + lx + 1;                  // index in the padded cell array
             S.cell_inc(home + 1);
             // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three)
-            uint32_t over = (cc[q] >> 8) & 0xFFu;
+            uint32_t over = (cc[q] >> kCodeOverlapShift) & 0xFFu;
             const uint32_t own = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? (1u << 19) : 0u;
             S.hm[s] = (uint32_t)home | (over << 11) | own;
 #pragma unroll
@@ -1409,7 +1411,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             if constexpr (L::kLid) S.lid[sl] = lidq;
             const int home = (ly + 1) * PX + lx + 1;
             S.cell_inc(home + 1);
-            uint32_t over = (cc >> 8) & 0xFFu;
+            uint32_t over = (cc >> kCodeOverlapShift) & 0xFFu;
             const uint32_t own = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? (1u << 19) : 0u;
             S.hm[sl] = (uint32_t)home | (over << 11) | own;
 #pragma unroll
@@ -1891,7 +1893,6 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);
     const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
     const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane((int)owned_word);
-    const int rel_mask = stale ? -1 : 7;
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
     // stragglers: the lists of the 32x32 tiles this tile covers (one, or two side by side for a 64-cell-wide tile)
     constexpr int NPAR = TX / 32;
@@ -1987,10 +1988,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * NT;
-            const uint32_t rb = ORD ? blk[q] % (uint32_t)NBLK : blk[q];
-            lxq[q] = (int)(rb % NBX) * 8 + (((int)(cc[q] & 15u) - kDriftLeft) & rel_mask) - (kHalo - HX);
-            lyq[q] = (int)(rb / NBX) * 8 + (((int)((cc[q] >> 4) & 15u) - kDriftDown) & rel_mask) - (kHalo - HY);
-            keep[q] = s < P && lxq[q] >= 0 && lxq[q] < RWX && lyq[q] >= 0 && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
+            lxq[q] = code_window_x(cc[q], ox);
+            lyq[q] = code_window_y(cc[q], oy);
+            keep[q] = s < P && lxq[q] < RWX && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
             if constexpr (ORD) keep[q] = keep[q] && (A.gtable == nullptr || blk[q] >= (uint32_t)NBLK || lidq[q] < n_owned);   // (see process_tile)
             mq[q] = __ballot(keep[q]);
             cnt += (uint32_t)__popcll(mq[q]);
@@ -2006,7 +2006,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         }
 #pragma unroll
         for (int q = 0; q < QP; ++q)
-            if (keep[q]) insert(slot[q], pp[q], pr[q], pid[q], lidq[q], lxq[q], lyq[q], (cc[q] >> 8) & 0xFFu);
+            if (keep[q]) insert(slot[q], pp[q], pr[q], pid[q], lidq[q], lxq[q], lyq[q], (cc[q] >> kCodeOverlapShift) & 0xFFu);
     }
 #pragma unroll
     for (int pi = 0; pi < NPAR; ++pi)
@@ -2030,7 +2030,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         const uint32_t sl = base + popc_below_lane(mk);
         keep = keep && sl < (uint32_t)L::kSlots;
-        if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, (cc >> 8) & 0xFFu);
+        if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, (cc >> kCodeOverlapShift) & 0xFFu);
     }
     __syncthreads();
     GPE_STAMP(1);
