@@ -276,6 +276,9 @@ struct NativeState {
     uint32_t *exc_count = nullptr;   // straggler lists: [2][exc_tiles] counts, then [2][exc_tiles][16] entries (one allocation)
     uint2 *exc_entry = nullptr;
     uint64_t exc_tiles = 0, exc_cap = 0;
+    uint4 *roster_hdr = nullptr;           // tile rosters (k_native.hip, CollideArgs)
+    uint32_t *roster_ids = nullptr;
+    uint64_t roster_cap = 0;
     int32_t exc_tiles_x = 0, exc_tiles_y = 0;
     const uint32_t *exc_count_now = nullptr;   // the set the current step's tiles read (NULL: the step sorts anyway)
     const uint2 *exc_entry_now = nullptr;
@@ -472,6 +475,7 @@ struct OnesweepGate {
     uint64_t table_pairs = 0;
     uint32_t *fresh = nullptr;
     uint32_t *sorts = nullptr;
+    uint32_t *sorts_seen = nullptr;        // last pass: copy of the new *sorts (a word nobody updates atomically while tiles read it)
     int ticket_base = 0;                   // tile tickets at ctl[ticket_base + pass]
     const uint32_t *count_now = nullptr;   // first pass: *sorted_count = *count_now (NULL: n) -- the particles the grouping covers
     uint32_t *sorted_count = nullptr;

@@ -100,6 +100,7 @@ constexpr int kCtlFresh = 36;                  // [parity] the radix passes ran:
 constexpr int kCtlSorts = kNativeCtlSorts;     // steps whose radix passes ran (running count, gpe_get_pipeline_info)
 constexpr int kCtlStragglers0 = 9, kCtlStragglers1 = 15;   // [parity] stragglers found by the step's hash so far
 constexpr int kCtlSortedCount = 32;            // particles the kept grouping covers (written by the first radix pass)
+constexpr int kCtlSortsSeen = 38;              // copy of kCtlSorts in the line the tiles only read (written by the last radix pass)
 constexpr int kCtlWords = 64;                  // tile_ctl is this long (two 128-byte lines)
 // How far a particle may have left the 8x8-cell block it was sorted into (cells beyond the block's extent, per
 // direction) and still be found by every tile that needs it.  A tile looks up the blocks of tile +- 8 cells but keeps
@@ -507,6 +508,9 @@ __global__ __launch_bounds__(kStreamBlock) void k_native_check_box(const float2 
 // ---------------------------------------------------------------------------------------------------
 // collide
 // ---------------------------------------------------------------------------------------------------
+#ifndef GPE_QMAX_MAIN_VALUE
+#define GPE_QMAX_MAIN_VALUE 3                  // looked-up particles per thread of a 32x32 tile's workgroup
+#endif
 struct CollideArgs {
     const float2 *pos_in;
     const float *radius;
@@ -544,8 +548,19 @@ struct CollideArgs {
     uint64_t n_owned;
     uint32_t fuse_verlet;
     VerletParams vp;
+    // Tile rosters (direct-slot tiles of a run that keeps its block table): the particles a tile's lookup finds do not
+    // change between two sorts, so the tile that looks them up right after a sort writes them down -- roster_ids[tile *
+    // kRosterCap ..], roster_hdr[tile] = (count | 0xFFFFFFFF: more than the tile stages, stamp = sorts so far + 1, largest
+    // 24x24-cell window population, -) -- and the steps until the next sort start from that list: one coalesced load
+    // issued with the kernel's first instructions instead of table lookup -> scan -> slot map -> ids (three barriers and
+    // a dependent global round trip).  A roster whose stamp is not the current one is ignored and rewritten.
+    uint4 *roster_hdr;           // NULL: no rosters
+    uint32_t *roster_ids;
+    const uint32_t *sorts_seen;  // tile_ctl[kCtlSortsSeen]
+    uint32_t roster_write;       // this run keeps its table: write rosters down
     unsigned long long *stamps;  // diagnostic builds only (-DGPE_TILE_STAMPS): cycles per phase, thread 0
 };
+constexpr int kRosterCap = GPE_QMAX_MAIN_VALUE * 512;   // == TileDirect<32, .., 512>::RAWCAP
 
 #ifdef GPE_TILE_STAMPS
 #define GPE_STAMP_BEGIN() long long _t_prev = clock64()
@@ -593,7 +608,7 @@ struct TileLds {
     // quarter's colour pass, not 512 threads' (100 M soak at step 1500: 22.9 ms with 1536, 22.2 with 1280, 24.3 /
     // 25.2 with 1700 / 1800 or 2048; profiles/r02/soak_1500_main_lookup_capacity.txt).
 #ifndef GPE_QMAX_MAIN
-#define GPE_QMAX_MAIN 3
+#define GPE_QMAX_MAIN GPE_QMAX_MAIN_VALUE
 #endif
     static constexpr int QMAX = T >= 32 ? GPE_QMAX_MAIN : (T >= 16 ? 6 : 8);
     static constexpr int RAWCAP = QMAX * kNatThreads;
@@ -1840,10 +1855,51 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     GPE_STAMP_BEGIN();
     const uint32_t fresh_word = *A.fresh;                              // (issued here, consumed behind P0: see process_tile)
     const uint32_t owned_word = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
+    // stragglers: the lists of the 32x32 tiles this tile covers (one, or two side by side for a 64-cell-wide tile)
+    constexpr int NPAR = TX / 32;
+    static_assert(TY == 32 && (TX == 32 || TX == 64), "straggler lists are kept per 32x32 tile");
+    uint32_t exc_word[NPAR];
+#pragma unroll
+    for (int pi = 0; pi < NPAR; ++pi) {
+        const int ptx = tx * NPAR + pi;
+        exc_word[pi] = (A.exc_count && ptx < A.exc_tiles_x) ? A.exc_count[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)ptx] : 0u;
+    }
+    // the tile's roster (CollideArgs): header, and the first ids on the chance that it is valid
+    constexpr bool kRoster = !ORD && TX == 32 && NT == 512;
+    constexpr int QP = QMAX >= 2 ? 2 : 1;
+    static_assert(!kRoster || L::RAWCAP == kRosterCap, "roster stride");
+    const bool rosters = kRoster && A.roster_hdr != nullptr;
+    const uint64_t roster_base = (uint64_t)((uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx) * (uint64_t)kRosterCap;
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t sorts_word = 0;
+    uint32_t first_ids[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) first_ids[q] = 0u;
+    if (rosters) {
+        hdr = A.roster_hdr[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx];
+        sorts_word = *A.sorts_seen;
+#pragma unroll
+        for (int q = 0; q < QP; ++q) first_ids[q] = A.roster_ids[roster_base + (uint32_t)tid + (uint32_t)q * NT];
+    }
 
     // ---- P0: clear the counters, look the region's blocks up, slot -> block map (as process_tile) ------------------
     for (int i = tid; i < (NZ + 1) / 2; i += NT) S.cntw[i] = 0;
     if (tid < 12) S.lcnt[tid] = 0;
+    const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
+    const uint32_t stamp_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorts_word) + 1u;
+    // (scalar) the roster is of the table in use: no lookup
+    const bool listed = rosters && stale && (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y) == stamp_now;
+    const bool record = rosters && !listed && A.roster_write != 0u;
+    if (listed) {
+        const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.x);
+        if (count == 0xFFFFFFFFu) return false;                        // more looked-up particles than the tile stages
+        const uint32_t wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);
+        if (tid == 0) {
+            S.misc[0] = count; S.misc[2] = 0; S.misc[3] = 0; S.misc[4] = 0;
+            if (wmax > kWindowReport) atomicMax(&A.tile_ctl[kCtlWindowMax], wmax);
+        }
+    } else {
+    if (tid == 0) S.misc[5] = 0;
     if (tid < VB) {
         const int rb = tid % NBLK;
         const int bi = rb % NBX, bj = rb / NBX;
@@ -1888,22 +1944,22 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #pragma unroll
             for (int di = 0; di < 3; ++di) w += S.bcnt[(wj + dj) * NBX + wi + di];
         if (w > kWindowReport) atomicMax(&A.tile_ctl[kCtlWindowMax], w);
+        if (record && w > kWindowReport) atomicMax(&S.misc[5], w);
     }
     __syncthreads();
-    const uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);
-    const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
+    }
+    const uint32_t P = listed ? (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.x)
+                              : (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);
     const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane((int)owned_word);
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
-    // stragglers: the lists of the 32x32 tiles this tile covers (one, or two side by side for a 64-cell-wide tile)
-    constexpr int NPAR = TX / 32;
-    static_assert(TY == 32 && (TX == 32 || TX == 64), "straggler lists are kept per 32x32 tile");
     uint32_t n_exc[NPAR];
 #pragma unroll
-    for (int pi = 0; pi < NPAR; ++pi) {
-        n_exc[pi] = 0;
-        const int ptx = tx * NPAR + pi;
-        if (stale && A.exc_count && ptx < A.exc_tiles_x)
-            n_exc[pi] = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.exc_count[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)ptx]), kExcSlots);
+    for (int pi = 0; pi < NPAR; ++pi)
+        n_exc[pi] = stale ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)exc_word[pi]), kExcSlots) : 0u;
+    if (record && tid == 0) {
+        // the header of the roster the gather below writes (an empty lookup is a valid, empty roster)
+        const uint32_t count = P > (uint32_t)L::RAWCAP ? 0xFFFFFFFFu : P;
+        A.roster_hdr[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx] = make_uint4(count, stamp_now, S.misc[5], 0u);
     }
     {
         // nothing of its own to write?  (see process_tile: own blocks with the table of this step; the whole lookup
@@ -1911,10 +1967,11 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         uint32_t any_exc = 0;
 #pragma unroll
         for (int pi = 0; pi < NPAR; ++pi) any_exc |= n_exc[pi];
-        if (stale ? (P == 0 && any_exc == 0) : S.misc[1] == 0) return true;
+        // (A tile that writes a roster goes through the gather for it even when nothing of this step's is its own.)
+        if (stale ? (P == 0 && any_exc == 0) : (S.misc[1] == 0 && !(record && P != 0))) return true;
     }
     if (P > (uint32_t)L::RAWCAP) return false;                         // more looked-up particles than slots
-    {
+    if (!listed) {
         constexpr int SHARE = (NT / VB) > 0 ? (NT / VB) : 1;
         for (int b = tid % VB, sub = tid / VB; sub < SHARE && b < VB; b += NT) {
             const uint32_t lo = S.boff[b], hi = S.boff[b + 1];
@@ -1955,17 +2012,34 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             file(zx + kk % 3 - 1, zy + kk / 3 - 1, s);
         }
     };
-    constexpr int QP = QMAX >= 2 ? 2 : 1;
     for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QP * NT) {
         uint32_t pid[QP], blk[QP], cc[QP];
         float2 pp[QP];
         float pr[QP];
+        if (listed) {                                                  // (scalar)
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const uint32_t sr = s0 + (uint32_t)tid + (uint32_t)q * NT;
+                blk[q] = 0u;
+                uint32_t v = first_ids[q];
+                if (s0 != 0) v = A.roster_ids[roster_base + min(sr, P - 1u)];
+                pid[q] = sr < P ? v : 0u;                              // (what lies behind the roster's end is not an id)
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < QP; ++q) {                                 // branch-free, all loads in flight: see process_tile
             const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * NT, P - 1u);
             blk[q] = S.sblk[s];
             const uint32_t *ids = (ORD && blk[q] >= (uint32_t)NBLK) ? A.gsorted_ids : A.sorted_ids;
             pid[q] = ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
+        }
+        if (record) {
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const uint32_t sr = s0 + (uint32_t)tid + (uint32_t)q * NT;
+                if (sr < P) A.roster_ids[roster_base + sr] = pid[q];
+            }
+        }
         }
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
@@ -2296,6 +2370,8 @@ void native_release(gpe_ctx *c)
     if (N.codes) (void)hipFree(N.codes);
     if (N.sorted_key) (void)hipFree(N.sorted_key);
     if (N.exc_count) (void)hipFree(N.exc_count);
+    if (N.roster_hdr) (void)hipFree(N.roster_hdr);
+    if (N.roster_ids) (void)hipFree(N.roster_ids);
     if (N.gkeys) (void)hipFree(N.gkeys);
     if (N.gids) (void)hipFree(N.gids);
     if (N.gkeys_b) (void)hipFree(N.gkeys_b);
@@ -2407,6 +2483,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         g.need = N.tile_ctl + kCtlNeedSort + parity;
         g.fresh = N.tile_ctl + kCtlFresh + parity;
         g.sorts = N.tile_ctl + kCtlSorts;
+        g.sorts_seen = N.tile_ctl + kCtlSortsSeen;
         if (gated) {
             g.key_copy = N.sorted_key; g.table_reset = (uint4 *)N.block_table; g.table_pairs = pairs;
             g.count_now = hg.owned; g.sorted_count = N.tile_ctl + kCtlSortedCount;
@@ -2544,6 +2621,24 @@ gpe_status native_configure(gpe_ctx *c)
         // (entries behind the counts of both sets, 8-byte aligned)
         N.exc_entry = (uint2 *)(N.exc_count + ((2 * N.exc_tiles + 1) & ~1ull));
         GPE_HIP(c, hipMemsetAsync(N.exc_count, 0, 2 * N.exc_tiles * sizeof(uint32_t), c->stream));
+    }
+    if (!c->shard.on && (c->cfg.flags & (GPE_FLAG_SORT_EVERY_STEP | GPE_FLAG_COUNTING_SORT_TILES | GPE_FLAG_WIDE_TILES)) == 0) {
+        // tile rosters (CollideArgs): 16 + 4 kRosterCap bytes per 32x32 tile.  Optional: a device that has no room for
+        // them runs without (every step then looks its blocks up)
+        if (N.roster_cap < N.exc_tiles) {
+            if (N.roster_hdr) GPE_HIP(c, hipFree(N.roster_hdr));
+            if (N.roster_ids) GPE_HIP(c, hipFree(N.roster_ids));
+            N.roster_hdr = nullptr; N.roster_ids = nullptr; N.roster_cap = 0;
+            hipError_t e1 = hipMalloc((void **)&N.roster_hdr, N.exc_tiles * sizeof(uint4));
+            hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&N.roster_ids, N.exc_tiles * (size_t)kRosterCap * sizeof(uint32_t)) : e1;
+            if (e1 != hipSuccess || e2 != hipSuccess) {
+                (void)hipGetLastError();
+                if (N.roster_hdr) (void)hipFree(N.roster_hdr);
+                N.roster_hdr = nullptr; N.roster_ids = nullptr;
+            } else N.roster_cap = N.exc_tiles;
+        }
+        // (stamp 0 is never current: the tiles compare with sorts + 1)
+        if (N.roster_hdr) GPE_HIP(c, hipMemsetAsync(N.roster_hdr, 0, N.exc_tiles * sizeof(uint4), c->stream));
     }
     if (N.overflow_cap < tiles) {
         if (N.overflow1) GPE_HIP(c, hipFree(N.overflow1));
@@ -2712,6 +2807,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.exc_count = N.exc_count_now;
     A.exc_entry = N.exc_entry_now;
     A.exc_tiles_x = N.exc_tiles_x;
+    A.roster_hdr = (N.roster_cap >= N.exc_tiles) ? N.roster_hdr : nullptr;
+    A.roster_ids = N.roster_ids;
+    A.sorts_seen = N.tile_ctl + kCtlSortsSeen;
+    A.roster_write = N.exc_count_now != nullptr ? 1u : 0u;            // (this step could do without a sort: the table is kept)
     A.table = N.block_table;
     A.entries = N.table_entries;
     A.blocks_x = N.blocks_x;

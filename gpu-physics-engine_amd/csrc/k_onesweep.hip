@@ -204,7 +204,8 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
     }
     if (G.fresh && tile == 0 && threadIdx.x == 0) {                  // last pass: the table is of this step
         *G.fresh = 1u;
-        atomicAdd(G.sorts, 1u);
+        const uint32_t before = atomicAdd(G.sorts, 1u);
+        if (G.sorts_seen) *G.sorts_seen = before + 1u;
     }
     // hist_src (the native step): the producer of the keys left the digit histograms (kHistCopies copies) and no
     // bases -- every tile sums and scans its pass's 256 bins itself, the loads in flight beside the keys'.  That takes
