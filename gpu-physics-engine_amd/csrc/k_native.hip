@@ -1984,6 +1984,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     // ---- P1: gather, keep, and file every membership straight into its cell's slots ---------------------------------
     // one membership: the counter's old value is the slot; the seventh member of a cell goes to the side list
     auto file = [&](const int zx, const int zy, const uint32_t s) {
+#ifdef GPE_DBG_SKIP
+        if (GPE_DBG_SKIP & 4) return;
+#endif
         if ((unsigned)zx < (unsigned)ZX && (unsigned)zy < (unsigned)ZY) {
             const int zc = zy * ZX + zx;
             const uint32_t k = S.cnt_inc(zc);
@@ -2012,6 +2015,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             file(zx + kk % 3 - 1, zy + kk / 3 - 1, s);
         }
     };
+#ifdef GPE_DBG_SKIP
+    if (!(GPE_DBG_SKIP & 64))                                          // diagnostic builds: phase cost by omission (results wrong)
+#endif
     for (uint32_t s0 = 0; s0 < P; s0 += (uint32_t)QP * NT) {
         uint32_t pid[QP], blk[QP], cc[QP];
         float2 pp[QP];
@@ -2138,6 +2144,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         for (int q = 0; q < QOWN; ++q) {
             own_prev[q] = make_float2(0.f, 0.f);
             if (q >= 1 && PS <= (uint32_t)q * NT) continue;
+#ifdef GPE_DBG_SKIP
+            if (GPE_DBG_SKIP & 32) continue;
+#endif
             if (A.fuse_verlet) own_prev[q] = A.prev[fetch[q]];
         }
     }
@@ -2145,6 +2154,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     // ---- P4: active cells per colour (the walk of process_tile over the 2 x 2 colour groups; a cell's member count is
     //          its counter).  List entry: zone cell | class data << 12: cells of 2-3 members (one lane each; bit 12: three)
     //          from the front, cells of 4-6 (a lane group; members - 4) from the back; cells of 7-64 in the wave list.
+#ifdef GPE_DBG_SKIP
+    if (!(GPE_DBG_SKIP & 2))
+#endif
     {
         constexpr int ZW = ZX / 2, ZH = ZY / 2, QC = ZW * ZH;
         static_assert(QC == QZ && NZ < 4096, "list entries: 12 bits of cell");
@@ -2212,6 +2224,11 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         const uint32_t work = single_base + ns;
         for (uint32_t i0 = 0; i0 < work; i0 += NT) {
             const uint32_t i = i0 + (uint32_t)tid;
+#ifdef GPE_DBG_SKIP
+            if (GPE_DBG_SKIP & 1) continue;
+            if ((GPE_DBG_SKIP & 8) && i < group_lanes) continue;
+            if ((GPE_DBG_SKIP & 16) && i >= group_lanes) continue;
+#endif
             if (i < group_lanes) {
                 const uint32_t en = S.list[k * QZ + (QZ - 1) - (i / kGroupLanes)];
                 resolve_group(S, (en & 0xFFFu) * kDirectSlots, (en >> 12) + kGroupMin, (int)(i % kGroupLanes), A.stiffness);
@@ -2252,6 +2269,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     // ---- P6: write the tile's own particles back, K12 applied (as process_tile) ---------------------------------------
 #pragma unroll
     for (int q = 0; q < QOWN; ++q) {
+#ifdef GPE_DBG_SKIP
+        if (GPE_DBG_SKIP & 32) continue;
+#endif
         const uint32_t id = own_id[q];
         if (id == 0xFFFFFFFFu) continue;
         const uint32_t s = (uint32_t)tid + (uint32_t)q * NT;
