@@ -126,13 +126,15 @@ class Context:
 
 
 class GpuBuffer:
-    """utils/gpu_buffer.rs:7-29 for u32 data: device buffer + host mirror (`data()`)."""
+    """utils/gpu_buffer.rs:7-29 for u32 data: device buffer + host mirror (`data()`).  Like the reference's, the device
+    buffer grows by doubling (gpu_buffer.rs:54-76) and keeps its DEVICE contents when it does."""
 
     def __init__(self, ctx, data):
         self.ctx = ctx
         self._data = np.ascontiguousarray(data, dtype=np.uint32).copy()
+        self._cap_bytes = max(1, self._data.nbytes)
         self.dptr = C.c_void_p()
-        ctx.call("gpe_buffer_alloc", max(1, self._data.nbytes), C.byref(self.dptr))
+        ctx.call("gpe_buffer_alloc", self._cap_bytes, C.byref(self.dptr))
         ctx.call("gpe_buffer_upload", self.dptr, _ptr(self._data), self._data.nbytes)
 
     def len(self):
@@ -141,20 +143,58 @@ class GpuBuffer:
     def data(self):
         return self._data
 
+    def capacity_bytes(self):
+        return self._cap_bytes
+
+    def _at(self, index):
+        return C.c_void_p(self.dptr.value + 4 * int(index))
+
     def download(self):
         """gpu_buffer.rs:96-175: read the device buffer back into the host mirror."""
         self.ctx.call("gpe_buffer_download", self.dptr, _ptr(self._data), self._data.nbytes)
         return self._data
 
+    def download_last(self):
+        """gpu_buffer.rs:177-262: the last element as the DEVICE holds it (None for an empty buffer); the mirror stays."""
+        if len(self._data) == 0:
+            return None
+        out = np.zeros(1, np.uint32)
+        self.ctx.call("gpe_buffer_download", self._at(len(self._data) - 1), _ptr(out), 4)
+        return int(out[0])
+
+    def _append(self, values):
+        # gpu_buffer.rs:49-87 (`upload`): a buffer that is too small is replaced by one of twice the needed size, the old
+        # device contents are carried over (buffer-to-buffer copy there; through the host here: the C-ABI has no
+        # device-to-device copy and this is off the step path), then only the new tail is written
+        values = np.ascontiguousarray(values, np.uint32).reshape(-1)
+        old_n = len(self._data)
+        need = 4 * (old_n + len(values))
+        if need > self._cap_bytes:
+            kept = np.zeros(old_n, np.uint32)
+            self.ctx.call("gpe_buffer_download", self.dptr, _ptr(kept), kept.nbytes)
+            fresh = C.c_void_p()
+            self.ctx.call("gpe_buffer_alloc", 2 * max(need, 1), C.byref(fresh))
+            self.ctx.call("gpe_buffer_upload", fresh, _ptr(kept), kept.nbytes)
+            self.ctx.call("gpe_buffer_free", self.dptr)
+            self.dptr, self._cap_bytes = fresh, 2 * max(need, 1)
+        self._data = np.concatenate([self._data, values])
+        self.ctx.call("gpe_buffer_upload", self._at(old_n), _ptr(values), values.nbytes)
+
+    def push(self, value):
+        """gpu_buffer.rs:30-33."""
+        self._append([value])
+
     def push_all(self, values):
-        """gpu_buffer.rs:177-226: append, reallocating the device buffer."""
-        old = self.download().copy()
-        new = np.concatenate([old, np.asarray(values, np.uint32)])
-        self.ctx.call("gpe_buffer_free", self.dptr)
-        self._data = new
-        self.dptr = C.c_void_p()
-        self.ctx.call("gpe_buffer_alloc", new.nbytes, C.byref(self.dptr))
-        self.ctx.call("gpe_buffer_upload", self.dptr, _ptr(new), new.nbytes)
+        """gpu_buffer.rs:35-38."""
+        self._append(values)
+
+    def replace_elem(self, new_data, index):
+        """gpu_buffer.rs:264-275: one element of the mirror and of the device buffer."""
+        if index < 0 or index >= len(self._data):
+            raise IndexError("Index out of bounds")                    # (the reference panics)
+        self._data[index] = np.uint32(new_data)
+        one = np.array([new_data], np.uint32)
+        self.ctx.call("gpe_buffer_upload", self._at(index), _ptr(one), 4)
 
     def free(self):
         if self.dptr:

@@ -15,6 +15,7 @@
 //   State                      -> gpe::State            state.rs:21-31 (update() == gpe_step)
 #pragma once
 
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <stdexcept>
@@ -75,41 +76,71 @@ class Context {
     gpe_ctx *ctx_ = nullptr;
 };
 
-// utils/gpu_buffer.rs:7-29 : a device buffer plus its host mirror (`data()`); download() refreshes the mirror.
+// utils/gpu_buffer.rs:7-29 : a device buffer plus its host mirror (`data()`); download() refreshes the mirror.  Like the
+// reference's, the device buffer grows by doubling (gpu_buffer.rs:54-76) and keeps its DEVICE contents when it does.
 template <typename T>
 class GpuBuffer {
    public:
-    GpuBuffer(const Context &ctx, std::vector<T> data) : ctx_(&ctx), data_(std::move(data)) { upload(); }
+    GpuBuffer(const Context &ctx, std::vector<T> data) : ctx_(&ctx), data_(std::move(data))
+    {
+        cap_bytes_ = std::max<size_t>(1, data_.size() * sizeof(T));
+        ctx_->call(gpe_buffer_alloc(ctx_->raw(), cap_bytes_, &dptr_));
+        ctx_->call(gpe_buffer_upload(ctx_->raw(), dptr_, data_.data(), data_.size() * sizeof(T)));
+    }
     ~GpuBuffer() { if (dptr_) gpe_buffer_free(ctx_->raw(), dptr_); }
     GpuBuffer(const GpuBuffer &) = delete;
     GpuBuffer &operator=(const GpuBuffer &) = delete;
-    GpuBuffer(GpuBuffer &&o) noexcept : ctx_(o.ctx_), data_(std::move(o.data_)), dptr_(o.dptr_) { o.dptr_ = nullptr; }
+    GpuBuffer(GpuBuffer &&o) noexcept : ctx_(o.ctx_), data_(std::move(o.data_)), dptr_(o.dptr_), cap_bytes_(o.cap_bytes_) { o.dptr_ = nullptr; }
     size_t len() const { return data_.size(); }
     const std::vector<T> &data() const { return data_; }
+    size_t capacity_bytes() const { return cap_bytes_; }
     T *device() const { return static_cast<T *>(dptr_); }
     const std::vector<T> &download()                                   // gpu_buffer.rs:96-175
     {
         ctx_->call(gpe_buffer_download(ctx_->raw(), dptr_, data_.data(), data_.size() * sizeof(T)));
         return data_;
     }
-    void push_all(const std::vector<T> &values)                        // gpu_buffer.rs:177-226
+    // gpu_buffer.rs:177-262: the last element as the DEVICE holds it; false for an empty buffer.  The mirror stays.
+    bool download_last(T *out) const
     {
-        download();
-        data_.insert(data_.end(), values.begin(), values.end());
-        if (dptr_) ctx_->call(gpe_buffer_free(ctx_->raw(), dptr_));
-        dptr_ = nullptr;
-        upload();
+        if (data_.empty()) return false;
+        ctx_->call(gpe_buffer_download(ctx_->raw(), device() + (data_.size() - 1), out, sizeof(T)));
+        return true;
+    }
+    void push(const T &value) { append(&value, 1); }                   // gpu_buffer.rs:30-33
+    void push_all(const std::vector<T> &values) { append(values.data(), values.size()); }   // gpu_buffer.rs:35-38
+    void replace_elem(const T &new_data, size_t index)                 // gpu_buffer.rs:264-275 (the reference panics)
+    {
+        if (index >= data_.size()) throw std::out_of_range("Index out of bounds");
+        data_[index] = new_data;
+        ctx_->call(gpe_buffer_upload(ctx_->raw(), device() + index, &new_data, sizeof(T)));
     }
 
    private:
-    void upload()
+    // gpu_buffer.rs:49-87 (`upload`): a buffer that is too small is replaced by one of twice the needed size, the old
+    // device contents are carried over (buffer-to-buffer copy there; through the host here: the C-ABI has no
+    // device-to-device copy and this is off the step path), then only the new tail is written
+    void append(const T *values, size_t count)
     {
-        ctx_->call(gpe_buffer_alloc(ctx_->raw(), data_.size() * sizeof(T) + 16, &dptr_));
-        ctx_->call(gpe_buffer_upload(ctx_->raw(), dptr_, data_.data(), data_.size() * sizeof(T)));
+        const size_t old_n = data_.size(), need = (old_n + count) * sizeof(T);
+        if (need > cap_bytes_) {
+            std::vector<T> kept(old_n);
+            ctx_->call(gpe_buffer_download(ctx_->raw(), dptr_, kept.data(), old_n * sizeof(T)));
+            void *fresh = nullptr;
+            const size_t cap = 2 * std::max<size_t>(need, 1);
+            ctx_->call(gpe_buffer_alloc(ctx_->raw(), cap, &fresh));
+            ctx_->call(gpe_buffer_upload(ctx_->raw(), fresh, kept.data(), old_n * sizeof(T)));
+            ctx_->call(gpe_buffer_free(ctx_->raw(), dptr_));
+            dptr_ = fresh;
+            cap_bytes_ = cap;
+        }
+        data_.insert(data_.end(), values, values + count);
+        ctx_->call(gpe_buffer_upload(ctx_->raw(), device() + old_n, values, count * sizeof(T)));
     }
     const Context *ctx_;
     std::vector<T> data_;
     void *dptr_ = nullptr;
+    size_t cap_bytes_ = 0;
 };
 
 // particles/particle_buffers.rs:4-10 (host copies as downloaded)

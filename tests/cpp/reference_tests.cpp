@@ -230,6 +230,36 @@ static void inclusive_prefix_sum_resize_test()                           // test
     ASSERT_EQ(buffer.download(), host_scan(original));
 }
 
+// ---- utils/gpu_buffer.rs:30-38,177-275: push / replace_elem / download_last (no reference test file covers them) --------
+static void gpu_buffer_push_replace_download_last()
+{
+    Context ctx;
+    GpuBuffer<uint32_t> buf(ctx, std::vector<uint32_t>{0, 1, 2, 3, 4});
+    uint32_t last = 0;
+    ASSERT_EQ(buf.capacity_bytes(), (size_t)20);
+    ASSERT_EQ(buf.download_last(&last), true);
+    ASSERT_EQ(last, 4u);
+    {
+        PrefixSum scan(ctx, buf);                                       // device: 0 1 3 6 10; the mirror keeps 0 1 2 3 4
+        scan.execute(5);
+    }
+    buf.push(77u);                                                      // grows to 48 bytes, device contents kept
+    ASSERT_EQ(buf.capacity_bytes(), (size_t)48);
+    buf.push_all(std::vector<uint32_t>{5, 6, 7});
+    ASSERT_EQ(buf.capacity_bytes(), (size_t)48);
+    buf.replace_elem(1234u, 2);
+    ASSERT_EQ(buf.download(), (std::vector<uint32_t>{0, 1, 1234, 6, 10, 77, 5, 6, 7}));
+    ASSERT_EQ(buf.download_last(&last), true);
+    ASSERT_EQ(last, 7u);
+    bool threw = false;
+    try { buf.replace_elem(1u, 9); } catch (const std::out_of_range &) { threw = true; }
+    ASSERT_EQ(threw, true);
+    GpuBuffer<uint32_t> empty(ctx, std::vector<uint32_t>{});
+    ASSERT_EQ(empty.download_last(&last), false);
+    empty.push(3u);
+    ASSERT_EQ(empty.download(), (std::vector<uint32_t>{3}));
+}
+
 // ---- beyond the reference: the whole step through State, both pipelines must agree ------------------------------------
 static void state_update_native_equals_compat()
 {
@@ -253,6 +283,7 @@ static void state_update_native_equals_compat()
 int main(int argc, char **argv)
 {
     const std::vector<std::pair<std::string, std::function<void()>>> tests = {
+        {"gpu_buffer_push_replace_download_last", gpu_buffer_push_replace_download_last},
         {"test_grid_build_cell_ids_with_multiple_particles", test_grid_build_cell_ids_with_multiple_particles},
         {"test_grid_build_cell_ids_and_sort", test_grid_build_cell_ids_and_sort},
         {"test_grid_build_cell_ids_sort_and_build_empty_collision_cells_list",

@@ -128,3 +128,34 @@ def test_scan_linearity_full_size(gpe, ctx):
         buf.free()
     assert np.array_equal(out[0] + out[1], out[2])
     assert out[2][-1] == np.uint32((a.sum(dtype=np.uint64) + b.sum(dtype=np.uint64)) & 0xFFFFFFFF)
+
+
+def test_gpu_buffer_push_replace_download_last(gpe, ctx):
+    """GpuBuffer::push / push_all / replace_elem / download_last (utils/gpu_buffer.rs:30-38,177-275): the device
+    buffer grows by doubling, keeps its DEVICE contents across the growth, and only the new tail is written."""
+    buf = gpe.GpuBuffer(ctx, np.arange(5, dtype=np.uint32))
+    assert buf.capacity_bytes() == 20 and buf.download_last() == 4
+    # something on the device that the host mirror does not know about (a kernel wrote it): it survives the growth
+    ctx.call("gpe_inclusive_scan_u32", buf.dptr, 5)                    # device: 0 1 3 6 10; mirror still 0 1 2 3 4
+    assert buf.download_last() == 10 and list(buf.data()) == [0, 1, 2, 3, 4]
+    buf.push(77)                                                       # 24 > 20 bytes: new buffer of 48
+    assert buf.len() == 6 and buf.capacity_bytes() == 48
+    assert buf.download_last() == 77
+    buf.push_all([5, 6, 7])                                            # 36 <= 48: in place
+    assert buf.capacity_bytes() == 48 and buf.len() == 9
+    buf.replace_elem(1234, 2)
+    assert list(buf.download()) == [0, 1, 1234, 6, 10, 77, 5, 6, 7]
+    with pytest.raises(IndexError):
+        buf.replace_elem(1, 9)
+    big = np.arange(100000, dtype=np.uint32)
+    buf.push_all(big)
+    assert buf.capacity_bytes() == 2 * 4 * (9 + 100000)
+    out = buf.download()
+    assert list(out[:9]) == [0, 1, 1234, 6, 10, 77, 5, 6, 7] and np.array_equal(out[9:], big)
+    assert buf.download_last() == 99999
+    empty = gpe.GpuBuffer(ctx, np.zeros(0, np.uint32))
+    assert empty.download_last() is None
+    empty.push(3)
+    assert empty.download_last() == 3 and list(empty.download()) == [3]
+    empty.free()
+    buf.free()
