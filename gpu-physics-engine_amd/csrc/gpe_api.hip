@@ -575,10 +575,12 @@ gpe_status gpe_get_pipeline_info(gpe_ctx *c, gpe_pipeline_info *info)
     out.compat_steps = N.compat_steps;
     out.window_max = N.host_stat ? N.host_stat[0] : 0u;
     if (N.tile_ctl) {
-        uint32_t sorts = 0;
+        uint32_t sorts = 0, seen = 0;
         GPE_HIP(c, hipMemcpyAsync(&sorts, N.tile_ctl + kNativeCtlSorts, sizeof(sorts), hipMemcpyDeviceToHost, c->stream));
+        GPE_HIP(c, hipMemcpyAsync(&seen, N.tile_ctl + kNativeCtlSortsSeen, sizeof(seen), hipMemcpyDeviceToHost, c->stream));
         GPE_HIP(c, hipStreamSynchronize(c->stream));
         out.native_sorts = sorts;
+        out.roster_stamp = seen;
     }
     memcpy(info, &out, info->struct_size);
     return GPE_OK;

@@ -252,7 +252,8 @@ struct OnesweepWorkspace {
     uint32_t hist_set = 0;           // which of the two sets of copies that is
 };
 
-constexpr int kNativeCtlSorts = 14;   // tile_ctl word: running count of steps whose radix passes ran (k_native.hip kCtlSorts)
+constexpr int kNativeCtlSorts = 14;         // tile_ctl word: running count of steps whose radix passes ran (k_native.hip kCtlSorts)
+constexpr int kNativeCtlSortsSeen = 38;     // its copy in the line the tiles only read (k_native.hip kCtlSortsSeen)
 // Native (N-key sort + LDS cell windows) pipeline state
 struct NativeState {
     bool eligible = false;           // every particle inside the world box, grid small enough, windows not over-dense
@@ -470,7 +471,9 @@ gpe_status onesweep_zero_hist(gpe_ctx *c);
 // the last one sets *fresh and counts the sort.  Passed by value to the pass kernel.
 struct OnesweepGate {
     const uint32_t *need = nullptr;
-    uint32_t *key_copy = nullptr;
+    uint32_t *key_copy = nullptr;           // first pass: key_copy[i] = (key % key_blocks_x) | (key / key_blocks_x) << 16
+    uint32_t key_blocks_x = 1;             //   (the block's coordinates in the block box: what the hash's drift test needs)
+    uint64_t key_div_magic = 0;            //   ceil(2^40 / key_blocks_x): key / key_blocks_x = key * magic >> 40, exact for key * blocks_x < 2^40
     uint4 *table_reset = nullptr;
     uint64_t table_pairs = 0;
     uint32_t *fresh = nullptr;

@@ -100,7 +100,7 @@ constexpr int kCtlFresh = 36;                  // [parity] the radix passes ran:
 constexpr int kCtlSorts = kNativeCtlSorts;     // steps whose radix passes ran (running count, gpe_get_pipeline_info)
 constexpr int kCtlStragglers0 = 9, kCtlStragglers1 = 15;   // [parity] stragglers found by the step's hash so far
 constexpr int kCtlSortedCount = 32;            // particles the kept grouping covers (written by the first radix pass)
-constexpr int kCtlSortsSeen = 38;              // copy of kCtlSorts in the line the tiles only read (written by the last radix pass)
+constexpr int kCtlSortsSeen = kNativeCtlSortsSeen;   // copy of kCtlSorts in the line the tiles only read (written by the last radix pass)
 constexpr int kCtlWords = 64;                  // tile_ctl is this long (two 128-byte lines)
 // How far a particle may have left the 8x8-cell block it was sorted into (cells beyond the block's extent, per
 // direction) and still be found by every tile that needs it.  A tile looks up the blocks of tile +- 8 cells but keeps
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     // beyond that go to per-tile straggler lists (kExcSlots); a list running over raises tile_ctl[kCtlNeedSort +
     // parity]; the radix passes that follow look at the word and return at once when it is 0.
     // sorted_key == NULL: always sort (first step, sharded runs, one-pass sorts).
+    (void)div_magic;                                                   // (the division moved to the radix pass that writes sorted_key)
     __shared__ uint32_t s_hist[4 * 256];
     __shared__ uint32_t s_ghist[GHOSTS ? 4 * 256 : 1];                 // (the ghosts' keys, sharded runs)
     __shared__ uint32_t s_sort_known;                                  // a wave of this workgroup has seen the straggler limit passed
@@ -347,7 +348,9 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 const bool out = (cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy) | (lbx < 0) | (lbx >= blocks_x) |
                                  (lby < 0) | (lby >= blocks_y);
                 oob |= out;
-                key = out ? 0u : (uint32_t)(lby * blocks_x + lbx);
+                // (24-bit multiply-add: both factors are below 2^13 for an in-box cell; a full-rate instruction where
+                // the 32-bit multiply takes four issue slots -- the kernel is bound by issue at 100 M, not by HBM)
+                key = out ? 0u : __umul24((uint32_t)lby, (uint32_t)blocks_x) + (uint32_t)lbx;
                 if (GHOSTS && ghost && G.gkeys) {
                     // a ghost: grouped by the ghosts' own sort; in the owned particles' sort it is padding
                     const uint64_t j = idx[u] - n_own;
@@ -356,12 +359,12 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 }
                 keys[idx[u]] = key;
                 // The particle's cell relative to the first cell of the block it was SORTED into: is it still within the
-                // reach of the tiles that find it through that block?  okey / blocks_x by a 64-bit multiply: exact for
-                // okey * blocks_x < 2^40 (keys < 2^27, blocks_x <= 2^13).
+                // reach of the tiles that find it through that block?
                 bool straggler = false;
                 if (sorted_key && !(GHOSTS && ghost && G.gkeys)) {
-                    const uint32_t oby = (uint32_t)(((uint64_t)okey[u] * div_magic) >> 40);
-                    const uint32_t obx = okey[u] - oby * (uint32_t)blocks_x;
+                    // (sorted_key holds the block's coordinates in the block box, x | y << 16: the radix pass that
+                    // copies the keys divides once per sort, k_onesweep.hip, instead of this kernel every step)
+                    const uint32_t obx = okey[u] & 0xFFFFu, oby = okey[u] >> 16;
                     const int32_t relx = cx - (int32_t)((obx + (uint32_t)bx0) << 3);
                     const int32_t rely = cy - (int32_t)((oby + (uint32_t)by0) << 3);
                     // out of reach of its old block, or not in the kept grouping at all (an arrival of a sharded run,
@@ -2441,11 +2444,14 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     // kept table reaches, every step) gains nothing from the kept table and pays for it in the hash kernel (the old
     // keys, the drift test: 1.2 instead of 0.6 ms at 100 M).  The passes' own counter says so (lagged): when three
     // quarters of the last 64 steps sorted, the next 256 steps sort unconditionally; then the table gets another try.
+    // (While the hold lasts every step sorts by decree, which says nothing about the scene: when it ends the count starts
+    // afresh -- one window for the lagged counter to settle, one to judge -- so a scene that has calmed down keeps its table.)
     if (N.host_stat && !always_sort) {
-        if (N.sort_hold > 0) --N.sort_hold;
-        if (++N.watch_steps >= 64) {
+        if (N.sort_hold > 0) {
+            if (--N.sort_hold == 0) { N.watch_steps = 0; N.watch_valid = false; }
+        } else if (++N.watch_steps >= 64) {
             const uint32_t sorts = N.host_stat[kStatSorts];
-            if (N.sort_hold == 0 && N.watch_valid && sorts - N.watch_sorts >= 48) N.sort_hold = 256;
+            if (N.watch_valid && sorts - N.watch_sorts >= 48) N.sort_hold = 256;
             N.watch_sorts = sorts; N.watch_steps = 0; N.watch_valid = true;
         }
     }
@@ -2506,6 +2512,8 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         g.sorts_seen = N.tile_ctl + kCtlSortsSeen;
         if (gated) {
             g.key_copy = N.sorted_key; g.table_reset = (uint4 *)N.block_table; g.table_pairs = pairs;
+            g.key_blocks_x = (uint32_t)N.blocks_x;
+            g.key_div_magic = ((1ull << 40) + (uint64_t)N.blocks_x - 1) / (uint64_t)N.blocks_x;
             g.count_now = hg.owned; g.sorted_count = N.tile_ctl + kCtlSortedCount;
         }
         GPE_TRY(onesweep_sort(c, N.keys, N.ids, N.keys_b, N.ids_b, n, N.passes, true, true, &sk, &sv, true,

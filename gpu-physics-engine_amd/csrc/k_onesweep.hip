@@ -194,7 +194,12 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
 #pragma unroll
         for (int k = 0; k < kOsItems; ++k) {
             const uint64_t idx = wave_base + (uint64_t)k * 64 + lane;
-            if (idx < n) G.key_copy[idx] = key[k];
+            if (idx < n) {
+                // (the block's coordinates in the block box, x | y << 16: what the hash kernel's drift test needs --
+                // one division per sort here instead of one per particle and step there)
+                const uint32_t by = (uint32_t)(((uint64_t)key[k] * G.key_div_magic) >> 40);
+                G.key_copy[idx] = (key[k] - by * G.key_blocks_x) | (by << 16);
+            }
         }
         for (uint64_t i = (uint64_t)tile * kOsBlock + threadIdx.x; i < G.table_pairs; i += (uint64_t)gridDim.x * kOsBlock)
             G.table_reset[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);   // (first, one past last) = (max, 0): empty
@@ -501,9 +506,10 @@ gpe_status onesweep_sort(gpe_ctx *c, uint32_t *keys, uint32_t *vals, uint32_t *k
             g.ticket_base = gate->ticket_base;
             if (p == 0) {
                 g.key_copy = gate->key_copy; g.table_reset = gate->table_reset; g.table_pairs = gate->table_pairs;
+                g.key_blocks_x = gate->key_blocks_x; g.key_div_magic = gate->key_div_magic;
                 g.count_now = gate->count_now; g.sorted_count = gate->sorted_count;
             }
-            if (last) { g.fresh = gate->fresh; g.sorts = gate->sorts; }
+            if (last) { g.fresh = gate->fresh; g.sorts = gate->sorts; g.sorts_seen = gate->sorts_seen; }
         }
         hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kOsBlock), 0, c->stream, ka, va, kb, vb, n,
                            (uint32_t)(8 * p), (uint32_t)p, ws.bases4, (u64 *)ws.status, ws.ctl, ws.epoch,

@@ -83,6 +83,12 @@ class Context:
         self.call("gpe_get_pipeline_info", C.byref(info))
         return {k: getattr(info, k) for k, _ in L.GpePipelineInfo._fields_ if k not in ("struct_size", "reserved")}
 
+    def device_ptr(self, what):
+        """gpe_device_ptr: (address, bytes) of a particle / grid array on the device (render hand-off, state.rs:150-176)."""
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        self.call("gpe_device_ptr", what, C.byref(ptr), C.byref(nbytes))
+        return ptr, nbytes.value
+
     def download(self, what, dtype, shape=None):
         nbytes = C.c_uint64()
         self.call("gpe_array_bytes", what, C.byref(nbytes))

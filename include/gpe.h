@@ -171,7 +171,8 @@ typedef struct gpe_pipeline_info {
     uint64_t compat_steps;       /* ... on the COMPAT kernels                                                      */
     uint64_t native_sorts;       /* NATIVE steps whose radix passes ran (the others reused the kept block table)   */
     uint32_t window_max;         /* largest 24x24-cell window population last reported by the tiles                */
-    uint32_t reserved;
+    uint32_t roster_stamp;       /* the sort count the tile rosters are checked against (the tiles' own copy of    */
+                                 /* native_sorts, low 32 bits: the two are equal or the rosters would be stale)    */
 } gpe_pipeline_info;
 gpe_status gpe_get_pipeline_info(gpe_ctx *ctx, gpe_pipeline_info *info);
 

@@ -650,3 +650,69 @@ def test_stragglers_flying_into_empty_space_are_not_lost(gpe, oracle):
     info = st.ctx.pipeline_info()
     assert info["native_steps"] == 45 and info["native_sorts"] < 30, info
     st.close(); sim.close()
+
+
+def test_roster_stamp_follows_every_sort(gpe):
+    """The tile rosters (ids written down by the tiles of a sort step) are valid only under the sort count they were
+    stamped with; the tiles compare against their own copy of that count, which every sort must bump -- whoever ran it:
+    a step that needed it, a step that sorts unconditionally (no roster is written then), the configuration's own sort.
+    (A copy that lags would let a step use the ids of an older grouping.)"""
+    n = 60_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=21)
+    for flags in (0, gpe._lib.FLAG_SORT_EVERY_STEP):
+        st = gpe.State(pos, rad, world=world, gravity=(0.0, -9.81), mode=gpe.MODE_NATIVE, flags=flags)
+        info = st.ctx.pipeline_info()
+        assert info["roster_stamp"] == info["native_sorts"] >= 1           # the configuration sorted once already
+        for chunk in range(4):
+            st.run(1 / 60, 30, resort_every=50, resort_first=(chunk == 0))
+            info = st.ctx.pipeline_info()
+            assert info["roster_stamp"] == info["native_sorts"] & 0xFFFFFFFF, (flags, chunk, info)
+        if flags:
+            assert info["native_sorts"] >= 120
+        st.close()
+
+
+def test_table_is_kept_again_after_a_spell_of_sorting_every_step(gpe):
+    """A cloud that flies 4.5 cells per step makes every step sort; after 128 such steps the library stops trying to keep
+    the block table (it sorts unconditionally for 256 steps: no old keys, no drift test, no rosters written).  The test
+    then stops the particles (prev = pos, written through the device pointer: the positions do not change).  When the
+    spell ends the table must be kept again -- few sorts from there on -- and the tiles must not start from rosters
+    written before the spell: the particles have moved hundreds of cells since.  Bit-identical to sorting every step."""
+    n = 60_000
+    world = (2600.0, 260.0)
+    rng = np.random.default_rng(77)
+    pos = np.empty((n, 2), np.float32)
+    pos[:, 0] = rng.random(n, dtype=np.float32) * np.float32(700.0) + np.float32(1.0)
+    pos[:, 1] = rng.random(n, dtype=np.float32) * np.float32(258.0) + np.float32(1.0)
+    rad = np.full(n, 0.5, np.float32)
+    prev = pos.copy()
+    prev[:, 0] -= np.float32(5.0)                                         # 5 units = 4.5 cells per step to the right
+
+    def run(flags):
+        st = gpe.State(pos, rad, world=world, gravity=(0.0, 0.0), mode=gpe.MODE_NATIVE, prev=prev, flags=flags)
+        marks = []
+        st.run(1 / 60, 140, resort_every=0, resort_first=True)
+        marks.append(st.ctx.pipeline_info()["native_sorts"])
+        # stop: prev = pos on the device (gpe_device_ptr + gpe_buffer_upload; positions untouched)
+        now = np.ascontiguousarray(st.positions())
+        ptr, nbytes = st.ctx.device_ptr(gpe._lib.PREV)
+        assert nbytes == now.nbytes
+        st.ctx.call("gpe_buffer_upload", ptr, now.ctypes.data_as(__import__("ctypes").c_void_p), now.nbytes)
+        st.run(1 / 60, 460, resort_every=0, resort_first=False)          # the rest of the spell, and the count afresh
+        marks.append(st.ctx.pipeline_info()["native_sorts"])
+        st.run(1 / 60, 200, resort_every=0, resort_first=False)
+        info = st.ctx.pipeline_info()
+        marks.append(info["native_sorts"])
+        out = (st.positions().copy(), st.previous_positions().copy(), marks, info)
+        st.close()
+        return out
+
+    p_keep, q_keep, marks, info = run(0)
+    p_sort, q_sort, marks_sort, _ = run(gpe._lib.FLAG_SORT_EVERY_STEP)
+    assert info["native_steps"] == 800 and info["compat_steps"] == 0
+    assert marks[0] >= 130                                                # the flight: (nearly) every step sorted
+    assert marks[2] - marks[1] <= 40, marks                               # the last 200 steps: the table is kept again
+    assert marks_sort[2] - marks_sort[1] == 200
+    assert info["roster_stamp"] == info["native_sorts"]
+    assert np.array_equal(p_keep, p_sort) and np.array_equal(q_keep, q_sort)
