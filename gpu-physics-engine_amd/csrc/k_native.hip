@@ -525,8 +525,8 @@ struct CollideArgs {
     const uint32_t *exc_count;   // stragglers handed to each 32x32 tile this step (NULL: none, the run always sorts)
     const uint2 *exc_entry;      // kExcSlots x (particle, cell x | y << 16) per tile
     int32_t exc_tiles_x;
-    const uint32_t *fresh;       // tile_ctl[kCtlFresh + parity]: != 0 when the radix passes ran this step (the table's
-                                 // blocks are the particles' blocks of NOW: relative cell = cell inside the block)
+    const uint32_t *fresh;       // tile_ctl[kCtlFresh + parity]: != 0 when the radix passes ran this step (the table is
+                                 // of NOW: nobody is a straggler, the lists and the rosters are not used)
     const uint2 *table;
     uint32_t entries;
     int32_t blocks_x, blocks_y;  // table index of block (bx, by) = (by - by0) * blocks_x + (bx - bx0)
@@ -2416,8 +2416,8 @@ static gpe_status arena_reserve(gpe_ctx *c, uint64_t want);
 // hash -> [sort -> block table].  *sorted_ids receives the particle ids grouped by 8x8-cell block.
 // The radix passes are enqueued every step but run only when the hash kernel finds a particle that has left the
 // reach of the grouping they last produced (kDrift* cells beyond its block): the sorted ids and the block table are
-// kept across steps, the per-particle codes say where each particle is relative to its old block, and the tiles look up
-// more blocks than they keep particles from.  Decided on the device, step by step; the host waits for nothing.
+// kept across steps, the per-particle codes carry the particle's cell (mod 128) and whether it is still within reach of
+// its old block, and the tiles look up more blocks than they keep particles from.  Decided on the device, step by step; the host waits for nothing.
 // In the benchmark cloud (gravity off) a sort is needed every few dozen steps, in free fall every 5-25 steps.
 // always_sort: this call must not rely on the kept grouping (configuration-time probes).
 static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool always_sort = false)
