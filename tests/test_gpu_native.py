@@ -716,3 +716,85 @@ def test_table_is_kept_again_after_a_spell_of_sorting_every_step(gpe):
     assert marks_sort[2] - marks_sort[1] == 200
     assert info["roster_stamp"] == info["native_sorts"]
     assert np.array_equal(p_keep, p_sort) and np.array_equal(q_keep, q_sort)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_api_sequences_native_equals_compat(gpe, seed):
+    """The same random sequence of boundary calls -- fused steps with and without a re-sort, gpe_run, the module calls one
+    by one (Grid::update / solve_collisions / update_positions), Morton re-sorts, mouse and gravity changes, new
+    particles (same and larger radii: a new cell size), a device pointer handed out, downloads -- on a NATIVE and on a
+    COMPAT context.  The native pipeline carries state from step to step (sorted ids, block table, straggler lists,
+    tile rosters, lagged policies); whatever a host does in between, the two contexts must hold the same bits."""
+    import ctypes
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(6_000, 14_000))
+    world = (float(rng.integers(160, 300)), float(rng.integers(90, 170)))
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
+    a = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    b = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
+    both = (a, b)
+    log = []
+    for op_index in range(60):
+        op = int(rng.integers(0, 12))
+        if op <= 2:
+            k = int(rng.integers(1, 6)); resort = bool(rng.integers(0, 4) == 0)
+            for st in both:
+                for s in range(k):
+                    st.update(1 / 60, resort=(resort and s == 0))
+            log.append("step x%d%s" % (k, " resort" if resort else ""))
+        elif op == 3:
+            k = int(rng.integers(5, 40)); every = int(rng.choice([0, 7, 16]))
+            for st in both:
+                st.run(1 / 60, k, resort_every=every, resort_first=False)
+            log.append("run %d every %d" % (k, every))
+        elif op == 4:
+            for st in both:
+                st.grid.update(); st.collision_system.solve_collisions(); st.particles.update_positions(1 / 60)
+            log.append("module calls")
+        elif op == 5:
+            for st in both:
+                st.particles.sort_by_cell_id()
+            log.append("morton resort")
+        elif op == 6:
+            pressed = bool(rng.integers(0, 2)); at = (float(rng.random() * world[0]), float(rng.random() * world[1]))
+            for st in both:
+                st.particles.mouse_click_callback(pressed, at)
+            log.append("mouse %s" % pressed)
+        elif op == 7:
+            g = (float(rng.choice([0.0, 3.0, -3.0])), float(rng.choice([0.0, -9.81, 9.81])))
+            for st in both:
+                st.ctx.call("gpe_set_gravity", g[0], g[1])
+            log.append("gravity %s" % (g,))
+        elif op == 8:
+            m = int(rng.integers(1, 300))
+            big = rng.integers(0, 5) == 0
+            p_new, r_new = gpe.scenes.mixed_radius_cloud(m, world, seed=int(rng.integers(1 << 30)),
+                                                         radii=(0.5, 1.0, 1.5) if big else (0.5,))
+            # (inside the box whatever the radius: the integration clamps to [r, world - r])
+            p_new = np.clip(p_new, 2.0, np.array(world, np.float32) - 2.0).astype(np.float32)
+            for st in both:
+                st.add_particles(p_new, r_new)
+            log.append("add %d%s" % (m, " mixed radii" if big else ""))
+        elif op == 9:
+            for st in both:
+                ptr, nbytes = st.ctx.device_ptr(gpe._lib.POS)
+                assert nbytes == 8 * st.particles.len()
+            log.append("device ptr")
+        elif op == 10:
+            # a host that writes through the pointer it was given: stop every particle (prev = pos)
+            for st in both:
+                now = np.ascontiguousarray(st.positions())
+                ptr, _ = st.ctx.device_ptr(gpe._lib.PREV)
+                st.ctx.call("gpe_buffer_upload", ptr, now.ctypes.data_as(ctypes.c_void_p), now.nbytes)
+            log.append("prev = pos")
+        else:
+            pa, pb = a.positions(), b.positions()
+            assert np.array_equal(pa, pb), (seed, op_index, log)
+            log.append("download")
+    assert np.array_equal(a.positions(), b.positions()), (seed, log)
+    assert np.array_equal(a.previous_positions(), b.previous_positions()), (seed, log)
+    assert np.array_equal(a.radii(), b.radii())
+    info = a.ctx.pipeline_info()
+    assert info["roster_stamp"] == info["native_sorts"] & 0xFFFFFFFF
+    assert info["native_steps"] > 0, log
+    a.close(); b.close()
