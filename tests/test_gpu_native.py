@@ -730,6 +730,13 @@ def test_random_api_sequences_native_equals_compat(gpe, seed):
     n = int(rng.integers(6_000, 14_000))
     world = (float(rng.integers(160, 300)), float(rng.integers(90, 170)))
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
+    if seed % 2 == 0:
+        # a region at four times the density: its tiles hold more than the direct-slot form stages (over-capacity
+        # launch, rosters that say "too many"), and it spreads over the neighbouring tiles as the run goes on
+        m = n // 2
+        corner = np.array([rng.random() * (world[0] - 60.0) + 5.0, rng.random() * (world[1] - 50.0) + 5.0], np.float32)
+        blob = (rng.random((m, 2), dtype=np.float32) * np.array([50.0, 40.0], np.float32) + corner).astype(np.float32)
+        pos = np.concatenate([pos, blob]); rad = np.concatenate([rad, np.full(m, 0.5, np.float32)])
     a = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
     b = gpe.State(pos, rad, world=world, mode=gpe.MODE_COMPAT)
     both = (a, b)
