@@ -794,6 +794,18 @@ def test_random_api_sequences_native_equals_compat(gpe, seed):
                 ptr, _ = st.ctx.device_ptr(gpe._lib.PREV)
                 st.ctx.call("gpe_buffer_upload", ptr, now.ctypes.data_as(ctypes.c_void_p), now.nbytes)
             log.append("prev = pos")
+        elif op == 11 and op_index % 3 == 0:
+            # ... and one that moves particles: a tenth of them teleported to random places inside the box
+            cnt = a.particles.len()
+            who = rng.choice(cnt, size=max(1, cnt // 10), replace=False)
+            where = (rng.random((len(who), 2), dtype=np.float32) * (np.array(world, np.float32) - 4.0) + 2.0).astype(np.float32)
+            for st in both:
+                now = np.ascontiguousarray(st.positions())
+                now[who] = where
+                for what in (gpe._lib.POS, gpe._lib.PREV):
+                    ptr, _ = st.ctx.device_ptr(what)
+                    st.ctx.call("gpe_buffer_upload", ptr, now.ctypes.data_as(ctypes.c_void_p), now.nbytes)
+            log.append("teleport %d" % len(who))
         else:
             pa, pb = a.positions(), b.positions()
             assert np.array_equal(pa, pb), (seed, op_index, log)
