@@ -397,6 +397,7 @@ class ShardedState:
             self.out_splits[p] = words(cm, cg)
             ro += words(cm, cg)
         self.send_words, self.recv_words = so, ro
+        self._check_segment_agreement()
         s = len(nb)                                                           # this rank's own segment: not sent
         cg_self = sum(plan.send_cap_mig[i] for i in range(len(nb)))
         plan.slot_rank[s], plan.send_off[s], plan.send_cap_mig[s], plan.send_cap_gho[s] = rank, so, 0, cg_self
@@ -414,6 +415,25 @@ class ShardedState:
             # stream is torch's own (GpeEngine.__init__), so that record stays valid past gpe_destroy
             self.send_host = torch.zeros(so, dtype=torch.int32).pin_memory()
             self.recv_host = torch.zeros(ro, dtype=torch.int32).pin_memory()
+
+    def _check_segment_agreement(self):
+        """Every segment a rank sends must be exactly as long as the peer expects it: a grouped ncclSend / ncclRecv
+        pair of different lengths does not fail, it waits.  Both sides compute the capacities from the same inputs
+        (the decomposition, the all-reduced block densities), so this can only trip on a configuration that differs
+        between the ranks (an environment variable, a library version) -- raise on every rank instead of hanging."""
+        if self.ws <= 1:
+            return
+        mine = torch.tensor(self.in_splits, dtype=torch.int64)              # words this rank sends to each rank
+        dev = self.e.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        rows = [torch.zeros(self.ws, dtype=torch.int64, device=dev) for _ in range(self.ws)]
+        dist.all_gather(rows, mine.to(dev), group=self.group)
+        sent_to_me = [int(rows[p][self.rank].item()) for p in range(self.ws)]
+        bad = [(p, sent_to_me[p], self.out_splits[p]) for p in range(self.ws) if sent_to_me[p] != self.out_splits[p]]
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            raise ValueError("sharded run: rank %d and its neighbours disagree on the segment sizes (peer, words it "
+                             "sends, words expected): %s -- the ranks were configured differently" % (self.rank, bad or "none here"))
 
     def _setup_transport(self):
         """Who moves the packed segments between the ranks (gpe_shard_exchange, called by gpe_shard_run):

@@ -190,6 +190,43 @@ def test_device_exchange_overflow_is_loud(gpe, tmp_path):
         assert "segment overflowed" in msg, msg
 
 
+def _disagree_worker(rank, ws, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GPE_SHARD_CAP_SCALE"] = "1" if rank == 0 else "0.5"      # the ranks are configured differently
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        n, world = 40_000, (420.0, 300.0)
+        pos, rad = gpe.scenes.uniform_cloud(n, world, seed=5)
+        dec = sharded.Decomposition(world, np.float32(0.5) * np.float32(2.2), ws)
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, device=0)
+        msg = "no error"
+        try:
+            sharded.ShardedState(eng, dec, rank, device_exchange=True)
+        except ValueError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write(msg)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_that_disagree_on_segment_sizes_fail_together(gpe, tmp_path):
+    """A send and a receive of different lengths would not fail, they would wait for each other for ever (RCCL) or
+    scramble the rows (all_to_all): the set-up compares what every rank sends with what its peer expects and raises
+    on EVERY rank."""
+    port = _free_port()
+    mp.spawn(_disagree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg = open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read()
+        assert "disagree on the segment sizes" in msg, msg
+
+
 def _teardown_worker(rank, ws, port, do_close):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
