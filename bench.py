@@ -14,6 +14,10 @@ that is already resident in HBM when the timed region starts.  Default workload 
 configs[1]: 1M particles, gravity off, the reference's 3048 x 1048 world.  The 100M-particle
 configuration (configs[2]) is measured in the same run and reported under "extra_workloads".
 
+`value` is what a long-lived host sees: the K-step windows follow each other from step W of the run until 2000
+steps have been timed (re-sorts and radix sorts inside), value = all timed steps / all timed seconds.  The figure
+of a fresh cloud (the same K steps restarted from a snapshot, as rounds 1-3 reported) is `value_fresh_cloud`.
+
 One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel: algorithmic bytes per launch
 ("Kernels and rooflines") / its mean launch time from hipEvent pairs recorded on the
 library's own stream inside the timed region.  `cpu_baseline` is the CPU oracle (a port of the
@@ -35,8 +39,10 @@ ALGO_BYTES_PER_PARTICLE = 148    # hash 12 + sort 68 + grid 8 + 
 RESORT_EVERY = 240               # 4 s at 60 Hz (particle_system.rs:13-14)
 PROFILE_EVERY = 10               # kernels of every 10th timed step are bracketed by HIP events (an event pair
                                  # per kernel on every step costs ~35% at 1M particles)
-MIN_TIMED_SECONDS = 0.5          # the K-step window is repeated until this much time has been measured (>= 1 window);
-MAX_WINDOWS = 400                # the MEDIAN window is reported: a 20-step window at 1M is 1.6 ms, too short alone
+HEADLINE_STEPS = 2000            # the K-step windows FOLLOW each other until this many steps of the run have been timed
+MAX_HEADLINE_SECONDS = 20.0      # ... or this much time (big particle counts); `value` = all timed steps / all timed seconds
+FRESH_SECONDS = 0.25             # N = 1: afterwards, windows restarted from the state after the warm-up (`value_fresh_cloud`)
+MAX_WINDOWS = 400
 
 
 class Schedule:
@@ -58,13 +64,16 @@ class Schedule:
             self.done += c; k -= c
 
 
-def timed_windows(sched, dt, steps, sync, dist, torch, min_seconds=MIN_TIMED_SECONDS, restore=None, max_steps=None):
+def timed_windows(sched, dt, steps, sync, dist, torch, min_seconds=0.0, restore=None, min_steps=0,
+                  max_seconds=MAX_HEADLINE_SECONDS):
     """EXACTLY `steps` steps per window, each window bracketed by barrier + synchronize on both sides and reduced
-    with MAX over the ranks; windows are repeated until min_seconds have been measured.  Returns the list of window
-    times (seconds).  Every rank runs the same number of windows (the count follows from all-reduced times).
+    with MAX over the ranks.  Returns the list of window times (seconds).  Every rank runs the same number of windows
+    (the count follows from all-reduced times).
+    restore is None: the windows FOLLOW each other -- the run a long-lived host sees, re-sorts every 240 steps of the
+    run included -- until min_steps steps have been timed (or max_seconds).
     restore: called before every window -- puts the system back to the state the first window starts from, so that
     every window times the SAME steps of the run (a cloud without damping relaxes: at 1M the step is 20 % slower after
-    4000 steps); without it the windows follow each other, at most max_steps steps in all."""
+    4000 steps); repeated until min_seconds have been measured."""
     times = []
     while True:
         if restore is not None:
@@ -84,9 +93,12 @@ def timed_windows(sched, dt, steps, sync, dist, torch, min_seconds=MIN_TIMED_SEC
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         times.append(el)
-        if sum(times) >= min_seconds or len(times) >= MAX_WINDOWS:
+        if len(times) >= MAX_WINDOWS or sum(times) >= max_seconds:
             return times
-        if max_steps is not None and (len(times) + 1) * steps > max_steps:
+        if restore is not None:
+            if sum(times) >= min_seconds:
+                return times
+        elif len(times) * steps >= min_steps:
             return times
 
 
@@ -94,7 +106,8 @@ def window_stats(times, steps):
     import statistics
     med = statistics.median(times)
     return {"windows": len(times), "steps_per_window": steps, "timed_steps_total": steps * len(times),
-            "timed_seconds_total": round(sum(times), 4), "median_window_ms": round(med * 1e3, 4),
+            "timed_seconds_total": round(sum(times), 4), "mean_window_ms": round(sum(times) / len(times) * 1e3, 4),
+            "median_window_ms": round(med * 1e3, 4),
             "first_window_ms": round(times[0] * 1e3, 4), "min_window_ms": round(min(times) * 1e3, 4),
             "max_window_ms": round(max(times) * 1e3, 4)}
 
@@ -108,10 +121,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--long-steps", type=int, default=2000,
-                    help="N = 1: the headline workload once more over this many timed steps (eight re-sorts inside the "
-                         "window; the cloud relaxes into touching clusters, so later steps resolve more pairs), "
-                         "reported under extra_workloads; 0 = skip")
+    ap.add_argument("--extra-tail", type=int, nargs="*", default=[500, 750, 1000],
+                    help="N = 1: the 100M run goes on to these step marks after its timed window; ms/step of every "
+                         "stretch is reported (the gravity-on scene falls, piles up and slows down)")
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--mode", choices=["compat", "native"], default=os.environ.get("GPE_BENCH_MODE", "native"))
     ap.add_argument("--gravity", choices=["off", "on"], default="off")
@@ -158,9 +170,14 @@ def kernel_rooflines(timings, n_particles, mode):
     return out
 
 
-def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gravity, device, min_seconds=MIN_TIMED_SECONDS):
-    """Returns (median seconds for `steps` steps over the timed windows, max over ranks; timings dict of rank 0; world;
-    window statistics; pipeline info)."""
+def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gravity, device, headline_steps=HEADLINE_STEPS,
+                 fresh_seconds=0.0, tail=()):
+    """Returns (mean seconds per `steps` steps over the timed windows, max over ranks; timings dict of rank 0; world;
+    window statistics; pipeline info; fresh-cloud statistics or None; tail marks).
+    The windows follow each other from step `warmup` of the run on (headline_steps in all; 0: one window).
+    fresh_seconds > 0: afterwards the state after `warmup` steps is put back again and again and the same `steps` steps
+    are timed for that long -- the figure of rounds 1-3 (no radix sort inside a window, freshly written rosters).
+    tail: after the windows, the run goes on to each of these step marks; ms/step of every stretch is reported."""
     import numpy as np
     world = gpe.scenes.world_for(n)
     t0 = time.time()
@@ -172,40 +189,58 @@ def run_workload(gpe, torch, dist, rank, world_size, n, steps, warmup, mode, gra
     del pos, rad
     dt = 1.0 / 60.0
     sched = Schedule(lambda d, k, every, first: st.run(d, k, resort_every=every, resort_first=first))
-    restore = None
-    if min_seconds > 0.0 and warmup >= 1:
-        # Repeated windows time the same steps [warmup, warmup + steps) of the run: the state after warmup - 1 steps is
-        # kept on the host, put back before every window (gpe_set_particles: ParticleSystem::new_from_buffers), and the
-        # last warm-up step runs again, untimed (like any first step on fresh buffers it sorts).
-        import ctypes
+    snap = None
+    if fresh_seconds > 0.0 and warmup >= 1:
+        # the state after warmup - 1 steps, kept on the host for the fresh-cloud windows below
         sched.advance(dt, warmup - 1)
         st.ctx.sync()
         snap = (np.ascontiguousarray(st.positions()), np.ascontiguousarray(st.previous_positions()),
                 np.ascontiguousarray(st.radii()), sched.done)
+        sched.advance(dt, 1)
+    else:
+        sched.advance(dt, warmup)           # first frame re-sorts
+    st.ctx.sync()
+    st.ctx.set_profiling(PROFILE_EVERY)     # HIP-event pairs around the kernels of every k-th step
+    st.ctx.reset_timings()
+    times = timed_windows(sched, dt, steps, st.ctx.sync, dist, torch, min_steps=headline_steps)
+    elapsed = sum(times) / len(times)
+    timings = st.ctx.timings()
+    pipe = st.ctx.pipeline_info()
+    marks = []
+    for m in tail:                          # the same run, further on (the 100M gravity scene falls and piles up)
+        k = m - sched.done
+        if k <= 0:
+            continue
+        st.ctx.sync()
+        t1 = time.perf_counter()
+        sched.advance(dt, k)
+        st.ctx.sync()
+        el = time.perf_counter() - t1
+        marks.append({"steps": [m - k, m], "ms_per_step": round(el / k * 1e3, 4), "steps_per_sec": round(k / el, 2)})
+        log("  steps %d-%d: %.3f ms/step" % (m - k, m, el / k * 1e3))
+    fresh = None
+    if snap is not None:
+        import ctypes
+        st.ctx.set_profiling(0)
         pv = lambda a: a.ctypes.data_as(ctypes.c_void_p)
 
         def restore():
+            # gpe_set_particles (ParticleSystem::new_from_buffers), then the last warm-up step again, untimed (like any
+            # first step on fresh buffers it sorts)
             st.ctx.call("gpe_set_particles", pv(snap[0]), pv(snap[1]), pv(snap[2]), len(snap[2]))
             sched.done = snap[3]
             sched.advance(dt, 1)
             st.ctx.sync()
-    else:
-        sched.advance(dt, warmup)           # first frame re-sorts
-        st.ctx.sync()
-    st.ctx.set_profiling(PROFILE_EVERY)     # HIP-event pairs around the kernels of every k-th step
-    st.ctx.reset_timings()
-    times = timed_windows(sched, dt, steps, st.ctx.sync, dist, torch, min_seconds, restore=restore)
-    import statistics
-    elapsed = statistics.median(times)
-    timings = st.ctx.timings()
-    pipe = st.ctx.pipeline_info()
+        import statistics
+        ft = timed_windows(sched, dt, steps, st.ctx.sync, dist, torch, min_seconds=fresh_seconds, restore=restore)
+        fresh = dict(window_stats(ft, steps), seconds_per_window=statistics.median(ft))
     p = st.positions()
     assert np.isfinite(p).all(), "non-finite positions after the run"
     st.close()
-    return elapsed, timings, world, window_stats(times, steps), pipe
+    return elapsed, timings, world, window_stats(times, steps), pipe, fresh, marks
 
 
-def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gravity, device, min_seconds=MIN_TIMED_SECONDS):
+def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gravity, device, headline_steps=HEADLINE_STEPS):
     """N > 1: one shard per GPU (gpu-physics-engine_amd/sharded.py): block ownership, one-block ghost band and
     migration over RCCL point-to-point every step.  Weak scaling: every rank fills its own rectangle of the
     world with n_per_gpu particles at the reference density."""
@@ -237,9 +272,8 @@ def run_sharded(gpe, torch, dist, rank, world_size, n_per_gpu, steps, warmup, gr
     eng.ctx.set_profiling(PROFILE_EVERY)
     eng.ctx.reset_timings()
     st.stats = {"migrants": 0, "ghosts": 0, "steps": 0}
-    times = timed_windows(sched, dt, steps, eng.sync, dist, torch, min_seconds, max_steps=max(steps, 240))
-    import statistics
-    elapsed = statistics.median(times)
+    times = timed_windows(sched, dt, steps, eng.sync, dist, torch, min_steps=headline_steps)
+    elapsed = sum(times) / len(times)
     timings = eng.ctx.timings()
     _, p, _ = st.owned()
     info = {"owned": st.n_owned, "process_grid": [px, py],
@@ -469,7 +503,8 @@ def log_timings(timings, roofs):
 
 
 def extra_entry(name, run, n_per_gpu, ngpu, steps, mode, resort_note, tj):
-    el, tim, world, wstats, info = run
+    el, tim, world, wstats, info = run[:5]
+    marks = run[6] if len(run) > 6 else None
     sps = steps / el
     roofline, roofs = roofline_block(tim, n_per_gpu, mode, tj)
     log_timings(tim, roofs)
@@ -488,6 +523,7 @@ def extra_entry(name, run, n_per_gpu, ngpu, steps, mode, resort_note, tj):
         "dominant_kernel_frac": roofline["frac"] if roofline else None,
         "pipeline": info if isinstance(info, dict) and "pipeline" in info else None,
         "sharding": info if isinstance(info, dict) and "pipeline" not in info else None,
+        "later_in_the_same_run": marks or None,
     }
 
 
@@ -577,21 +613,19 @@ def main():
 
     n = args.particles
     tj = load_traffic()
-    # The CPU baseline first (rank 0, N = 1): the GPU legs then run back to back at the end of the process.
-    cpu = None
-    if ngpu == 1 and not args.no_cpu_baseline:
-        log("cpu baseline (oracle) ...")
-        cpu = cpu_baseline(gpe, min(n, 1_000_000))
-        cpu["value"] = round(cpu["value"], 4)
-    shard_info, pipe = None, None
+    # The GPU legs first, back to back (a coarse utilisation sampler then sees them as one busy stretch); the CPU
+    # baseline (rank 0, N = 1) last.
+    shard_info, pipe, fresh = None, None, None
     if world_size > 1:
         elapsed, timings, world, shard_info = run_sharded(gpe, torch, dist, rank, world_size, n, args.steps,
-                                                          args.warmup, args.gravity, local_rank)
+                                                          args.warmup, args.gravity, local_rank,
+                                                          headline_steps=0 if args.single_window else HEADLINE_STEPS)
         wstats = shard_info.pop("windows")
     else:
-        elapsed, timings, world, wstats, pipe = run_workload(gpe, torch, dist, rank, world_size, n, args.steps, args.warmup,
-                                                             args.mode, args.gravity, local_rank,
-                                                             min_seconds=0.0 if args.single_window else MIN_TIMED_SECONDS)
+        elapsed, timings, world, wstats, pipe, fresh, _ = run_workload(
+            gpe, torch, dist, rank, world_size, n, args.steps, args.warmup, args.mode, args.gravity, local_rank,
+            headline_steps=0 if args.single_window else HEADLINE_STEPS,
+            fresh_seconds=0.0 if args.single_window else FRESH_SECONDS)
     # The 100M legs, shaped like BASELINE.json configs[2..4]: gravity on, warm-up 10 steps (the first re-sorts),
     # then timed windows with the re-sort every 240 steps of the run INSIDE them.
     extras = []
@@ -602,32 +636,29 @@ def main():
         if world_size > 1:
             per = max(1, ne // world_size)
             log("extra workload: %d particles in all over %d GPUs (%d per GPU), gravity on ..." % (per * world_size, world_size, per))
-            r = run_sharded(gpe, torch, dist, rank, world_size, per, xs, 10, "on", local_rank, min_seconds=0.0)
+            r = run_sharded(gpe, torch, dist, rank, world_size, per, xs, 10, "on", local_rank, headline_steps=0)
             extras.append(("%d particles over %d GPUs (%d per GPU), gravity on (0,-9.81)%s" %
                            (per * world_size, world_size, per, " = BASELINE.json configs[3]" if world_size == 4 else ""),
                            (r[0], r[1], r[2], r[3].pop("windows"), r[3]), per, sched, xs))
             log("extra workload: %d particles per GPU (%d in all), gravity on ..." % (ne, ne * world_size))
-            r = run_sharded(gpe, torch, dist, rank, world_size, ne, xs, 10, "on", local_rank, min_seconds=0.0)
+            r = run_sharded(gpe, torch, dist, rank, world_size, ne, xs, 10, "on", local_rank, headline_steps=0)
             extras.append(("%d particles per GPU, %d in all, gravity on (0,-9.81)%s" %
                            (ne, ne * world_size, " = BASELINE.json configs[4]" if world_size == 8 else ""),
                            (r[0], r[1], r[2], r[3].pop("windows"), r[3]), ne, sched, xs))
         else:
             log("extra workload: %d particles, gravity on ..." % ne)
             extras.append(("%d particles, gravity on (0,-9.81) = BASELINE.json configs[2]" % ne,
-                           run_workload(gpe, torch, None, 0, 1, ne, xs, 10, args.mode, "on", local_rank, min_seconds=0.0),
+                           run_workload(gpe, torch, None, 0, 1, ne, xs, 10, args.mode, "on", local_rank, headline_steps=0,
+                                        tail=tuple(m for m in args.extra_tail if m > 10 + xs)),
                            ne, sched, xs))
-            if args.long_steps > 0:
-                log("extra workload: the headline workload over %d steps ..." % args.long_steps)
-                extras.append(("%d particles, gravity %s, ONE window of %d timed steps: the headline workload over a long "
-                               "run (the cloud relaxes into touching clusters, later steps resolve more pairs)"
-                               % (n, args.gravity, args.long_steps),
-                               run_workload(gpe, torch, None, 0, 1, n, args.long_steps, args.warmup, args.mode,
-                                            args.gravity, local_rank, min_seconds=0.0), n,
-                               "warm-up %d steps (first one re-sorts), %d timed steps, re-sort every %d steps of the run"
-                               % (args.warmup, args.long_steps, RESORT_EVERY), args.long_steps))
     soak = None
     if args.soak and world_size == 1:
         soak = run_soak(gpe, torch, args.extra_particles, args.mode, local_rank)
+    cpu = None
+    if ngpu == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle) ...")
+        cpu = cpu_baseline(gpe, min(n, 1_000_000))
+        cpu["value"] = round(cpu["value"], 4)
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -648,11 +679,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u32",
         "data": "synthetic",
         "timed_steps_total": wstats["timed_steps_total"],
-        "timing": dict(wstats, value_is="the MEDIAN window of `steps` steps; windows (each bracketed by barrier + "
-                                        "synchronize, max over ranks) repeat until %.1f s have been measured; at n_gpus = 1 "
-                                        "every window starts from the same state (the one after `warmup` steps), at "
-                                        "n_gpus > 1 the windows follow each other, at most 240 steps in all"
-                                        % MIN_TIMED_SECONDS),
+        "timing": dict(wstats, value_is="ALL timed steps / ALL timed seconds: windows of `steps` steps (each bracketed by "
+                                        "barrier + synchronize, max over ranks) FOLLOW each other from step `warmup` of the run "
+                                        "until %d steps have been timed -- the Morton re-sort every %d steps of the run and "
+                                        "every radix sort a step needs fall inside the windows" % (HEADLINE_STEPS, RESORT_EVERY)),
         "config": {"workload": "%d particles per GPU, gravity %s, world %.1f x %.1f, radius 0.5, uniform random "
                                "(BASELINE.json configs[1] at 1M per GPU)" % (n, args.gravity, world[0], world[1]),
                    "particles_per_gpu": n, "particles_total": n * ngpu, "mode": mode, "resort_every": RESORT_EVERY,
@@ -670,6 +700,13 @@ def main():
                    "sharding": shard_info},
         "roofline": roofline,
     }
+    if fresh is not None:
+        # the figure rounds 1-3 reported as `value`: the same `steps` steps right behind the warm-up, restarted from a
+        # snapshot again and again (no radix sort inside a window, rosters freshly written)
+        result["value_fresh_cloud"] = round(args.steps / fresh["seconds_per_window"], 3)
+        result["fresh_cloud"] = dict({k: v for k, v in fresh.items() if k != "seconds_per_window"},
+                                     value_is="median window of `steps` steps, every window restarted from the state after "
+                                              "`warmup` steps (%.2f s of them)" % FRESH_SECONDS)
     if cpu is not None:
         result["cpu_baseline"] = cpu
     if extras:

@@ -296,7 +296,7 @@ struct NativeState {
     uint32_t step_seq = 0;           // native_prepare_step calls: its parity selects the per-step control words
     const uint32_t *fresh_word = nullptr;   // tile_ctl word the tiles of the current step read (did the passes run?)
     uint32_t reason = GPE_REASON_NO_PARTICLES;   // why the native kernels do not run (GPE_REASON_*), NONE when they do
-    uint64_t native_steps = 0, compat_steps = 0, sorts_base = 0;   // (sorts_base: device count at the last memset of tile_ctl)
+    uint64_t native_steps = 0, compat_steps = 0;
     bool always_sort = false;        // GPE_FLAG_SORT_EVERY_STEP (A/B measurements, tests): sort every step as rounds 1-2 did
     int32_t blocks_x = 0, blocks_y = 0;   // 8x8-cell blocks of the block box: table index = (by - by0) * blocks_x + (bx - bx0)
     int32_t bx0 = 0, by0 = 0;        // first block of the box (sharded runs: the rank's active box; else 0, 0)

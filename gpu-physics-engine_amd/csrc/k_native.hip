@@ -1712,12 +1712,19 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if constexpr (ORD) {                                       // S.id holds the order key: find the block of
                 const uint32_t raw = s;                                // the looked-up slot, re-read the local index
-                int lo = 0, hi = VB;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (S.boff[mid] <= raw) lo = mid; else hi = mid;
+                if (raw >= P) {
+                    // a straggler (filed behind the looked-up slots by P1): no block lists it -- its local index is
+                    // the entry of the tile's straggler list it came from
+                    const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
+                    id = A.exc_entry[(uint64_t)pt * kExcSlots + (raw - P)].x;
+                } else {
+                    int lo = 0, hi = VB;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (S.boff[mid] <= raw) lo = mid; else hi = mid;
+                    }
+                    id = (lo >= NBLK ? A.gsorted_ids : A.sorted_ids)[S.bstart[lo] + (raw - S.boff[lo])];
                 }
-                id = (lo >= NBLK ? A.gsorted_ids : A.sorted_ids)[S.bstart[lo] + (raw - S.boff[lo])];
             }
             const float2 c = make_float2(S.px[s], S.py[s]);
             if (A.fuse_verlet && id < n_owned) {
@@ -1764,15 +1771,36 @@ __device__ __forceinline__ void resolve_quarter(OverflowLds<ORD> &u, const Colli
         ok = process_tile<ORD>(u.spill, A, sx, sy);
         __syncthreads();
         if (ok) continue;
-        // the spill arena is exhausted: flag it (gpe_sync / gpe_download report the error) and pass the
-        // tile's own particles through unresolved so that the state stays finite
+        // The spill arena is exhausted: flag it (sticky; gpe_sync / gpe_download report the error and the state of
+        // this step is NOT a result) and pass the tile's own particles through unresolved and unintegrated, so that
+        // what a host reads back stays finite.  "Own" as P1 decides it -- by the home cell in the code word, not by
+        // block membership: with a kept table a block still lists particles that have drifted into a neighbouring
+        // tile (that tile writes them) and misses those that drifted in; stragglers come through the tile's list.
         if (threadIdx.x == 0) atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
-        for (int b = threadIdx.x; b < Spill::NBLK; b += kNatThreads) {
-            const int bi = b % Spill::NB, bj = b / Spill::NB;
-            if (bi < 1 || bi >= Spill::NB - 1 || bj < 1 || bj >= Spill::NB - 1) continue;
-            for (uint32_t q = 0; q < u.spill.bcnt[b]; ++q) {
-                const uint32_t id = A.sorted_ids[u.spill.bstart[b] + q];
-                A.pos_out[id] = A.pos_in[id];
+        {
+            constexpr int VBS = ORD ? 2 * Spill::NBLK : Spill::NBLK;
+            const int wx = sx * kTileSmall - Spill::HXL, wy = sy * kTileSmall - Spill::HYL;
+            const bool stale = *A.fresh == 0u;
+            const uint32_t owned_now = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
+            for (int b = threadIdx.x; b < VBS; b += kNatThreads) {
+                const uint32_t *ids = (ORD && b >= Spill::NBLK) ? A.gsorted_ids : A.sorted_ids;
+                for (uint32_t q = 0; q < u.spill.bcnt[b]; ++q) {
+                    const uint32_t id = ids[u.spill.bstart[b] + q];
+                    const uint32_t code = A.codes[id];
+                    const int lx = code_window_x(code, wx) - Spill::HXL, ly = code_window_y(code, wy) - Spill::HYL;
+                    bool own = lx >= 0 && lx < kTileSmall && ly >= 0 && ly < kTileSmall && !(stale && (code & kCodeStraggler));
+                    if (ORD) own = own && (A.gtable == nullptr || b >= Spill::NBLK || id < owned_now);
+                    if (own) A.pos_out[id] = A.pos_in[id];
+                }
+            }
+            if (stale && A.exc_count) {
+                const uint32_t pt = (uint32_t)((sy * kTileSmall) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((sx * kTileSmall) >> 5);
+                const uint32_t ne = min(A.exc_count[pt], kExcSlots);
+                for (uint32_t e = threadIdx.x; e < ne; e += kNatThreads) {
+                    const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + e];
+                    const int lx = (int)(en.y & 0xFFFFu) - sx * kTileSmall, ly = (int)(en.y >> 16) - sy * kTileSmall;
+                    if (lx >= 0 && lx < kTileSmall && ly >= 0 && ly < kTileSmall) A.pos_out[en.x] = A.pos_in[en.x];
+                }
             }
         }
         __syncthreads();
@@ -1858,15 +1886,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     GPE_STAMP_BEGIN();
     const uint32_t fresh_word = *A.fresh;                              // (issued here, consumed behind P0: see process_tile)
     const uint32_t owned_word = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
-    // stragglers: the lists of the 32x32 tiles this tile covers (one, or two side by side for a 64-cell-wide tile)
-    constexpr int NPAR = TX / 32;
-    static_assert(TY == 32 && (TX == 32 || TX == 64), "straggler lists are kept per 32x32 tile");
-    uint32_t exc_word[NPAR];
-#pragma unroll
-    for (int pi = 0; pi < NPAR; ++pi) {
-        const int ptx = tx * NPAR + pi;
-        exc_word[pi] = (A.exc_count && ptx < A.exc_tiles_x) ? A.exc_count[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)ptx] : 0u;
-    }
+    // stragglers handed to this tile by the hash kernel
+    static_assert(TY == 32 && TX == 32, "straggler lists and rosters are kept per 32x32 tile");
+    const uint32_t exc_word = A.exc_count ? A.exc_count[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx] : 0u;
     // the tile's roster (CollideArgs): header, and the first ids on the chance that it is valid
     constexpr bool kRoster = !ORD && TX == 32 && NT == 512;
     constexpr int QP = QMAX >= 2 ? 2 : 1;
@@ -1955,10 +1977,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                               : (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[0]);
     const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane((int)owned_word);
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
-    uint32_t n_exc[NPAR];
-#pragma unroll
-    for (int pi = 0; pi < NPAR; ++pi)
-        n_exc[pi] = stale ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)exc_word[pi]), kExcSlots) : 0u;
+    const uint32_t n_exc = stale ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)exc_word), kExcSlots) : 0u;
     if (record && tid == 0) {
         // the header of the roster the gather below writes (an empty lookup is a valid, empty roster)
         const uint32_t count = P > (uint32_t)L::RAWCAP ? 0xFFFFFFFFu : P;
@@ -1967,9 +1986,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     {
         // nothing of its own to write?  (see process_tile: own blocks with the table of this step; the whole lookup
         // region and the straggler lists with a kept table)
-        uint32_t any_exc = 0;
-#pragma unroll
-        for (int pi = 0; pi < NPAR; ++pi) any_exc |= n_exc[pi];
+        const uint32_t any_exc = n_exc;
         // (A tile that writes a roster goes through the gather for it even when nothing of this step's is its own.)
         if (stale ? (P == 0 && any_exc == 0) : (S.misc[1] == 0 && !(record && P != 0))) return true;
     }
@@ -2091,14 +2108,10 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         for (int q = 0; q < QP; ++q)
             if (keep[q]) insert(slot[q], pp[q], pr[q], pid[q], lidq[q], lxq[q], lyq[q], (cc[q] >> kCodeOverlapShift) & 0xFFu);
     }
-#pragma unroll
-    for (int pi = 0; pi < NPAR; ++pi)
-    if (n_exc[pi] != 0 && tid < 64) {                                  // stragglers handed to the tile (see process_tile)
-        bool have = (uint32_t)tid < n_exc[pi];
-        const uint32_t pt = (uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)(tx * NPAR + pi);
+    if (n_exc != 0 && tid < 64) {                                      // stragglers handed to the tile (see process_tile)
+        const bool have = (uint32_t)tid < n_exc;
+        const uint32_t pt = (uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx;
         const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + (have ? (uint32_t)tid : 0u)];
-        // (a cell inside both parents' windows is in both lists: the right-hand list only counts beyond the left one's window)
-        if (pi > 0) have = have && (int)(en.y & 0xFFFFu) > (tx * NPAR + pi - 1) * 32 + 31 + L::HXR;
         uint32_t pid = en.x;
         const float2 pp = A.pos_in[pid];
         const float pr = A.radius[pid];
@@ -2296,12 +2309,10 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #ifndef GPE_CAP_DIRECT
 #define GPE_CAP_DIRECT 928
 #endif
-#ifndef GPE_CAP_WIDE
-#define GPE_CAP_WIDE 2176
-#endif
-// TX x 32-cell tiles on NT threads: 32 x 32 on 512 (four workgroups per CU), or 64 x 32 on 1024 (two per CU; the window
-// is 1.32 x the tile's own cells instead of 1.48 x, the looked-up blocks 1.875 x instead of 2.25 x).  A tile the
-// window has no room for is listed for k_collide_overflow as its 32 x 32 tile(s).
+// 32 x 32-cell tiles on 512 threads, four workgroups per CU.  A tile the window has no room for is listed for
+// k_collide_overflow.  (64 x 32-cell tiles on 1024 threads -- two per CU, the window 1.32 x the tile's own cells instead of
+// 1.48 x -- were built, are exact and 5-6.5 % slower: profiles/r03/ab_wide_tiles_64x32_1024_threads_rejected.txt, the
+// code in profiles/r04/wide_tiles_64x32_removed.patch.)
 template <int TX, int CAP, bool ORD, int NT>
 __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
 {
@@ -2312,10 +2323,9 @@ __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
     if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
     const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
     if (!process_tile_direct<ORD>(S, A, tx, ty)) {
-        const uint32_t ptx = (uint32_t)tx * (TX / 32) + threadIdx.x;
-        if (threadIdx.x < TX / 32 && (TX == 32 || (int)ptx * 32 < A.gx)) {      // (a wide tile's right half may lie outside the box)
+        if (threadIdx.x == 0) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
-            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | ptx;
+            if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
             else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
         }
     }
@@ -2459,7 +2469,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     const bool kept_sharded = c->shard.on && c->shard.active && c->use_order_keys && N.gkeys != nullptr && !N.always_sort;
     const bool gated = N.passes >= 2 && (!sharded || kept_sharded);
     const bool reuse = gated && !always_sort && N.sort_state_valid && (kept_sharded || N.sorted_n == n) && !N.always_sort &&
-                       N.sort_hold == 0;
+                       N.sort_hold == 0 && N.exc_count != nullptr;     // (no room for the straggler lists: sort every step)
     const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;        // the table is allocated in 16-byte units
     HashGhosts hg;
     hg.sorted_count = N.tile_ctl + kCtlSortedCount;
@@ -2494,8 +2504,9 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
                            N.codes, N.passes, hist_now, hist_next, c->os_ws.ctl, N.tile_ctl,
                            (uint4 *)N.block_table, gated ? 0ull : pairs,    // gated: the first radix pass resets the table
                            N.host_stat, reuse ? N.sorted_key : nullptr, parity, div_magic,
-                           N.exc_count + (size_t)parity * N.exc_tiles, N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots,
-                           N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles, N.exc_tiles_x, N.exc_tiles_y,
+                           N.exc_count ? N.exc_count + (size_t)parity * N.exc_tiles : nullptr,
+                           N.exc_count ? N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots : nullptr,
+                           N.exc_count ? N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles : nullptr, N.exc_tiles_x, N.exc_tiles_y,
                            (uint32_t)std::max<uint64_t>(64, n >> 11),       // more stragglers than 0.05 % of the particles: sort
                            hg);
         GPE_HIP(c, hipGetLastError());
@@ -2537,7 +2548,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     N.sorted_n = n;
     N.fresh_word = N.tile_ctl + kCtlFresh + parity;
     N.exc_count_now = reuse ? N.exc_count + (size_t)parity * N.exc_tiles : nullptr;
-    N.exc_entry_now = N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots;
+    N.exc_entry_now = reuse ? N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots : nullptr;
     *sorted_ids = sv;
     return GPE_OK;
 }
@@ -2642,15 +2653,28 @@ gpe_status native_configure(gpe_ctx *c)
         if (N.exc_cap < N.exc_tiles) {
             if (N.exc_count) GPE_HIP(c, hipFree(N.exc_count));
             N.exc_count = nullptr; N.exc_entry = nullptr; N.exc_cap = 0;
+            // (264 B per tile and set: a sparse scene in a huge world -- up to 8 M tiles -- may not get them; the run
+            // then sorts every step, native_prepare_step, instead of failing to configure)
             const size_t bytes = 2 * N.exc_tiles * sizeof(uint32_t) + 16 + 2 * N.exc_tiles * kExcSlots * sizeof(uint2);
-            GPE_HIP(c, hipMalloc((void **)&N.exc_count, bytes));
-            N.exc_cap = N.exc_tiles;
+            if (hipMalloc((void **)&N.exc_count, bytes) == hipSuccess) N.exc_cap = N.exc_tiles;
+            else { (void)hipGetLastError(); N.exc_count = nullptr; }
         }
-        // (entries behind the counts of both sets, 8-byte aligned)
-        N.exc_entry = (uint2 *)(N.exc_count + ((2 * N.exc_tiles + 1) & ~1ull));
-        GPE_HIP(c, hipMemsetAsync(N.exc_count, 0, 2 * N.exc_tiles * sizeof(uint32_t), c->stream));
+        if (N.exc_count) {
+            // (entries behind the counts of both sets, 8-byte aligned)
+            N.exc_entry = (uint2 *)(N.exc_count + ((2 * N.exc_tiles + 1) & ~1ull));
+            GPE_HIP(c, hipMemsetAsync(N.exc_count, 0, 2 * N.exc_tiles * sizeof(uint32_t), c->stream));
+        }
     }
-    if (!c->shard.on && (c->cfg.flags & (GPE_FLAG_SORT_EVERY_STEP | GPE_FLAG_COUNTING_SORT_TILES | GPE_FLAG_WIDE_TILES)) == 0) {
+    // Rosters scale with the world's tile count, not with n (6160 B per tile): at the benchmark density that is 16 B per
+    // particle; a sparse scene in a large world would pay gigabytes for lists of a few ids each.  Beyond 16 roster
+    // slots per particle (4 x the benchmark's ratio) the run does without them.
+    const bool rosters_pay = N.exc_tiles * (uint64_t)kRosterCap <= 16ull * std::max<uint64_t>(c->n, 1u << 16);
+    if (!rosters_pay && N.roster_hdr) {
+        GPE_HIP(c, hipFree(N.roster_hdr)); GPE_HIP(c, hipFree(N.roster_ids));
+        N.roster_hdr = nullptr; N.roster_ids = nullptr; N.roster_cap = 0;
+    }
+    if (!c->shard.on && rosters_pay && N.exc_count &&
+        (c->cfg.flags & (GPE_FLAG_SORT_EVERY_STEP | GPE_FLAG_COUNTING_SORT_TILES)) == 0) {
         // tile rosters (CollideArgs): 16 + 4 kRosterCap bytes per 32x32 tile.  Optional: a device that has no room for
         // them runs without (every step then looks its blocks up)
         if (N.roster_cap < N.exc_tiles) {
@@ -2922,20 +2946,12 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
                 if (N.calm_steps >= 64) N.crowded = false;
             }
         }
-        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || A.order_keys != nullptr ||
-                            (N.crowded && (c->cfg.flags & GPE_FLAG_WIDE_TILES) == 0);
+        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || A.order_keys != nullptr || N.crowded;
         if (legacy) {
             if (A.order_keys)
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
             else
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
-        } else if ((c->cfg.flags & GPE_FLAG_WIDE_TILES) != 0) {
-            // 64 x 32-cell tiles: the tile grid in x is that of 64-cell columns
-            CollideArgs W = A;
-            W.tile_x0 = cx0 / 64;
-            W.tiles_x = cx1 / 64 - W.tile_x0 + 1;
-            const uint32_t wgrid = (((uint32_t)W.tiles_x * (uint32_t)W.tiles_y + 7u) / 8u) * 8u;
-            hipLaunchKernelGGL((k_collide_direct<64, GPE_CAP_WIDE, false, 1024>), dim3(wgrid), dim3(1024), 0, c->stream, W);
         } else {
             hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         }

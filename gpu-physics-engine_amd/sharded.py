@@ -197,7 +197,7 @@ class _DevArray:
 class GpeEngine:
     """One rank's particles inside a gpe context (native mode, order keys on)."""
 
-    def __init__(self, pos, rad, gid, world, gravity=(0.0, 0.0), device=0, capacity=None, profiling=False, flags=0):
+    def __init__(self, pos, rad, gid, world, gravity=(0.0, 0.0), device=0, capacity=None, profiling=False, flags=0, prev=None):
         from .engine import Context
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
@@ -212,7 +212,10 @@ class GpeEngine:
         n = pos.shape[0]
         if n == 0:
             raise ValueError("every rank needs at least one particle at start")
-        self.ctx.call("gpe_set_particles", pos.ctypes.data_as(C.c_void_p), None, rad.ctypes.data_as(C.c_void_p), n)
+        if prev is not None:
+            prev = np.ascontiguousarray(prev, np.float32).reshape(-1, 2)
+        self.ctx.call("gpe_set_particles", pos.ctypes.data_as(C.c_void_p),
+                      prev.ctypes.data_as(C.c_void_p) if prev is not None else None, rad.ctypes.data_as(C.c_void_p), n)
         self.ctx.call("gpe_use_order_keys", 1)
         self.reserve(capacity or int(n * 1.3) + 4096)
         self.n_owned = n

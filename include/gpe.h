@@ -78,9 +78,8 @@ enum {
     GPE_FLAG_NATIVE_STATS = 4u,      /* print the tile statistics to stderr every 128 steps                          */
     GPE_FLAG_SAFE_SORT = 8u,         /* per-module sorts by the communication-free reduce-then-scan radix sort       */
                                      /* (k_radix_sort.hip) instead of onesweep: an in-GPU cross-check                */
-    GPE_FLAG_COUNTING_SORT_TILES = 16u,/* NATIVE: the dense launch builds its member lists by a counting sort       */
+    GPE_FLAG_COUNTING_SORT_TILES = 16u /* NATIVE: the dense launch builds its member lists by a counting sort       */
                                      /* (rounds 1-2) instead of direct cell slots; for A/B timing                    */
-    GPE_FLAG_WIDE_TILES = 32u        /* NATIVE: 64 x 32-cell tiles on 1024 threads instead of 32 x 32 on 512         */
 };
 
 /* Fills *cfg with the reference's compile-time constants. */

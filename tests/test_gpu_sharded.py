@@ -482,3 +482,80 @@ def test_mixed_radii_ranks_agree_on_the_cell_size(gpe, tmp_path):
     order = np.argsort(gid)
     assert np.array_equal(np.concatenate(poss)[order], want_pos)
     assert np.array_equal(np.concatenate(prevs)[order], want_prev)
+
+
+def _spill_blob_scene():
+    """A sparse cloud of radius-0.5 particles plus 9000 particles of radius 0.01 packed into 12 x 12 units across the
+    cut between two ranks (block row 18 = y 158.4), all drifting up at 0.01 units per step: every 8x8-cell tile near
+    the blob looks up more particles than any LDS window stages (the global spill windows resolve them), a handful of
+    blob particles migrate to the upper rank every step, and nothing moves fast enough to force a sort."""
+    world = (420.0, 300.0)
+    rng = np.random.default_rng(99)
+    nb, nt = 40_000, 9_000
+    pos = np.empty((nb + nt, 2), np.float32)
+    pos[:nb] = (rng.random((nb, 2), dtype=np.float32) * np.array(world, np.float32)).astype(np.float32)
+    pos[nb:, 0] = np.float32(200.0) + rng.random(nt, dtype=np.float32) * np.float32(12.0)
+    pos[nb:, 1] = np.float32(152.0) + rng.random(nt, dtype=np.float32) * np.float32(12.0)
+    rad = np.full(nb + nt, 0.5, np.float32)
+    rad[nb:] = np.float32(0.01)
+    prev = pos.copy()
+    prev[nb:, 1] -= np.float32(0.01)
+    return world, pos, prev, rad
+
+
+def _spill_blob_worker(rank, ws, port, steps, resort_at, dt, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        gpe = importlib.import_module("gpu-physics-engine_amd")
+        sharded = importlib.import_module("gpu-physics-engine_amd.sharded")
+        world, pos, prev, rad = _spill_blob_scene()
+        dec = sharded.Decomposition(world, np.float32(0.5) * np.float32(2.2), ws)
+        mine = np.nonzero(dec.owner_of(pos) == rank)[0]
+        eng = sharded.GpeEngine(pos[mine], rad[mine], mine, world, device=0, prev=prev[mine])
+        st = sharded.ShardedState(eng, dec, rank, device_exchange=True)
+        assert st.fast
+        for s in range(steps):
+            st.update(dt, resort=(s in resort_at))
+        gid, p, q = st.owned()
+        eng.ctx.sync()
+        info = eng.ctx.pipeline_info()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=gid, pos=p, prev=q, n0=len(mine),
+                 native_sorts=info["native_sorts"], window_max=info["window_max"])
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_migrants_into_a_spill_window_on_a_step_that_keeps_its_table(gpe, tmp_path):
+    """A sharded run that keeps its block table, over a region so dense that its 8x8-cell tiles go through the global
+    spill windows, with particles arriving from the other rank on steps that do not sort: the arrivals are stragglers
+    (no block of the kept table lists them), the spill window files them behind its looked-up slots, and its write-back
+    must find their local index through the straggler list -- round 3 searched the block offsets for them and wrote
+    their result onto some other particle.  Bit-identical to the single-context run."""
+    ws, steps, dt, resort_at = 2, 12, 1 / 60, (0, 7)
+    mp.spawn(_spill_blob_worker, args=(ws, _free_port(), steps, resort_at, dt, str(tmp_path)), nprocs=ws, join=True)
+    world, pos, prev, rad = _spill_blob_scene()
+    ref = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE, prev=prev)
+    for s in range(steps):
+        ref.update(dt, resort=(s in resort_at))
+    want_pos, want_prev = ref.positions(), ref.previous_positions()
+    ref.close()
+    n = len(rad)
+    gids, poss, prevs, moved = [], [], [], 0
+    for r in range(ws):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        gids.append(d["gid"]); poss.append(d["pos"]); prevs.append(d["prev"])
+        moved += abs(len(d["gid"]) - int(d["n0"]))
+        assert int(d["native_sorts"]) < steps, "every step sorted: the kept table was never used (%d)" % int(d["native_sorts"])
+        # (the statistic counts a rank's OWNED particles per 24x24-cell window: about half the blob each; with the other
+        # half as ghosts every 8x8 tile near the blob looks up ~9000 particles, more than the 4096 an LDS window takes)
+        assert int(d["window_max"]) > 2500, "the blob never filled a spill window (%d)" % int(d["window_max"])
+    assert moved >= 20, "too few particles changed rank (%d)" % moved
+    gid = np.concatenate(gids)
+    assert np.array_equal(np.sort(gid), np.arange(n))
+    order = np.argsort(gid)
+    assert np.array_equal(np.concatenate(poss)[order], want_pos)
+    assert np.array_equal(np.concatenate(prevs)[order], want_prev)
