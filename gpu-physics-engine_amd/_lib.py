@@ -75,6 +75,33 @@ class GpeShardPlan(C.Structure):
 # gpe_shard_transport_fn
 SHARD_TRANSPORT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 COMM_ID_BYTES = 128
+SHARD_MAX_RANKS = 26
+REDUCE_SUM, REDUCE_MAX = 0, 1
+
+
+class GpeShardLayout(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("world_size", C.c_uint32), ("px", C.c_uint32), ("py", C.c_uint32),
+        ("world_width", C.c_float), ("world_height", C.c_float), ("cell_size", C.c_float),
+        ("cells_x", C.c_int32), ("cells_y", C.c_int32), ("blocks_x", C.c_int32), ("blocks_y", C.c_int32),
+        ("xcuts", C.c_int32 * 27), ("ycuts", C.c_int32 * 27),
+    ]
+
+
+# gpe_shard_collectives.all_reduce_u32 / .all_to_all_u32
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p)
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p,
+                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+
+
+class GpeShardCollectives(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("user", C.c_void_p),
+                ("all_reduce_u32", ALL_REDUCE_FN), ("all_to_all_u32", ALL_TO_ALL_FN)]
+
+
+class GpeShardStats(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("recuts", C.c_uint32), ("resorts", C.c_uint64), ("steps", C.c_uint64),
+                ("n_owned", C.c_uint64), ("n_ghost", C.c_uint64), ("n_neighbours", C.c_uint32), ("transport", C.c_uint32)]
 
 
 class GpeError(RuntimeError):
@@ -147,6 +174,22 @@ SYMBOLS = [
     ("gpe_shard_set_transport", _I32, [_VP, _VP, _VP]),
     ("gpe_shard_exchange", _I32, [_VP]),
     ("gpe_shard_run", _I32, [_VP, _F, _U64]),
+    ("gpe_shard_layout_build", _I32, [_F, _F, _F, _U32, _U32, _U32, _VP, _VP, C.POINTER(GpeShardLayout)]),
+    ("gpe_shard_layout_owner_of", _I32, [C.POINTER(GpeShardLayout), _VP, _U64, _VP]),
+    ("gpe_shard_quantile_cuts", _I32, [_VP, _U32, _U32, _U32, _VP]),
+    ("gpe_shard_set_collectives", _I32, [_VP, C.POINTER(GpeShardCollectives)]),
+    ("gpe_local_group_create", _I32, [_U32, C.POINTER(_VP)]),
+    ("gpe_local_group_destroy", _I32, [_VP]),
+    ("gpe_local_group_join", _I32, [_VP, _VP, _U32]),
+    ("gpe_local_group_abort", _I32, [_VP]),
+    ("gpe_shard_set_particles", _I32, [_VP, _VP, _VP, _VP, _VP, _U64, _U64]),
+    ("gpe_shard_setup", _I32, [_VP, C.POINTER(GpeShardLayout), _U32, _F]),
+    ("gpe_shard_get_layout", _I32, [_VP, C.POINTER(GpeShardLayout)]),
+    ("gpe_shard_resort", _I32, [_VP]),
+    ("gpe_shard_recut", _I32, [_VP, _F, C.POINTER(_I32)]),
+    ("gpe_shard_run_scheduled", _I32, [_VP, _F, _U64, _U64, _I32]),
+    ("gpe_shard_download_owned", _I32, [_VP, _VP, _VP, _VP, _U64, C.POINTER(_U64)]),
+    ("gpe_shard_get_stats", _I32, [_VP, C.POINTER(GpeShardStats)]),
     ("gpe_set_profiling", _I32, [_VP, _U32]),
     ("gpe_reset_timings", _I32, [_VP]),
     ("gpe_get_timings", _I32, [_VP, C.POINTER(GpeTiming), C.POINTER(_U32)]),

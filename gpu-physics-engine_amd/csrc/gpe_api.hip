@@ -406,6 +406,7 @@ static gpe_status do_step(gpe_ctx *c, float dt, uint32_t flags)
 }
 
 gpe_status step_for_shard(gpe_ctx *c, float dt) { return do_step(c, dt, 0u); }
+gpe_status resort_for_shard(gpe_ctx *c) { return do_resort(c); }
 gpe_status grow_for_shard(gpe_ctx *c, uint64_t capacity) { return grow_particle_buffers(c, capacity); }
 
 }  // namespace gpe
@@ -502,6 +503,8 @@ gpe_status gpe_destroy(gpe_ctx *c)
     scan_release(c);
     onesweep_release(c);
     native_release(c);
+    group_leave(c);
+    ctl_release(c);
     comm_release(c);
     shard_release(c);
     // a stream lent by gpe_set_stream belongs to the caller (a host framework may still hold buffers and

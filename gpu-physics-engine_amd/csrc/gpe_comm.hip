@@ -30,6 +30,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;               // why loading failed
 };
@@ -54,6 +55,7 @@ static RcclApi *rccl_api()
             {"ncclCommDestroy", (void **)&api.CommDestroy}, {"ncclGroupStart", (void **)&api.GroupStart},
             {"ncclGroupEnd", (void **)&api.GroupEnd},       {"ncclSend", (void **)&api.Send},
             {"ncclRecv", (void **)&api.Recv},               {"ncclGetErrorString", (void **)&api.GetErrorString},
+            {"ncclAllReduce", (void **)&api.AllReduce},
         };
         for (auto &s : syms) {
             *s.slot = dlsym(api.handle, s.name);
@@ -94,6 +96,43 @@ void comm_release(gpe_ctx *c)
 static uint64_t segment_words(uint32_t cap_mig, uint32_t cap_gho)
 {
     return 4ull + 6ull * cap_mig + 4ull * cap_gho;      // header, migrant rows, ghost rows (k_shard.hip)
+}
+
+// The control plane's two collectives over the communicator (gpe_shard_ctl.hip): ncclAllReduce in place, and the
+// all-to-all as one group of ncclSend / ncclRecv pairs (what a rank keeps for itself is a device copy).
+gpe_status rccl_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op)
+{
+    RcclApi *api = nullptr;
+    GPE_TRY(rccl_ready(c, &api));
+    GPE_NCCL(c, api, api->AllReduce(d_buf, d_buf, count, ncclUint32, op == GPE_REDUCE_MAX ? ncclMax : ncclSum,
+                                     (ncclComm_t)c->shard.comm, c->stream));
+    return GPE_OK;
+}
+
+gpe_status rccl_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
+                               uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt)
+{
+    RcclApi *api = nullptr;
+    GPE_TRY(rccl_ready(c, &api));
+    const ncclComm_t comm = (ncclComm_t)c->shard.comm;
+    const uint32_t ws = c->ctl.layout.world_size, me = c->ctl.rank;
+    if (send_cnt[me] != recv_cnt[me]) return fail(c, GPE_ERR_INVALID_ARG, "all_to_all: the rank's own send and receive counts differ");
+    if (send_cnt[me])
+        GPE_HIP(c, hipMemcpyAsync(d_recv + recv_off[me], d_send + send_off[me], send_cnt[me] * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, c->stream));
+    GPE_NCCL(c, api, api->GroupStart());
+    ncclResult_t first_bad = ncclSuccess;
+    for (uint32_t p = 0; p < ws; ++p) {
+        if (p == me) continue;
+        ncclResult_t r = ncclSuccess;
+        if (send_cnt[p]) r = api->Send(d_send + send_off[p], send_cnt[p], ncclUint32, (int)p, comm, c->stream);
+        if (r == ncclSuccess && recv_cnt[p]) r = api->Recv(d_recv + recv_off[p], recv_cnt[p], ncclUint32, (int)p, comm, c->stream);
+        if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r;
+    }
+    const ncclResult_t end = api->GroupEnd();
+    if (first_bad != ncclSuccess) return fail(c, GPE_ERR_HIP, std::string("ncclSend/ncclRecv: ") + api->GetErrorString(first_bad));
+    if (end != ncclSuccess) return fail(c, GPE_ERR_HIP, std::string("ncclGroupEnd: ") + api->GetErrorString(end));
+    return GPE_OK;
 }
 
 }  // namespace gpe
@@ -179,6 +218,14 @@ gpe_status gpe_shard_exchange(gpe_ctx *c)
         const int32_t rc = S.transport(S.transport_user, S.send, S.recv, (void *)c->stream);
         if (rc != 0) return fail(c, GPE_ERR_HIP, "gpe_shard_exchange: the caller's transport failed");
         return GPE_OK;
+    }
+    if (S.slots.n_slots <= 1) return GPE_OK;                           // no neighbour: nothing to move
+    // a plan made by gpe_shard_setup knows the exchange as an all-to-all: the caller's collectives or the local group
+    if (c->ctl.ready && S.send == c->ctl.d_send) {
+        if (c->ctl.coll_set)
+            return coll_all_to_all_u32(c, c->ctl.d_send, c->ctl.x_send_off, c->ctl.x_send_cnt, c->ctl.d_recv, c->ctl.x_recv_off,
+                                       c->ctl.x_recv_cnt);
+        if (c->ctl.group) return group_exchange_segments(c);
     }
     if (!S.comm)
         return fail(c, GPE_ERR_STATE, "gpe_shard_exchange: no communicator (gpe_shard_comm_init / _attach) and no transport");

@@ -352,6 +352,38 @@ struct ShardState {
     void *transport_user = nullptr;
 };
 
+// The sharded run's control plane (gpe_shard_ctl.hip): the decomposition this context is a rank of, the tables and
+// segment buffers it owns, and who carries its collectives.
+struct ShardCtl {
+    bool ready = false;              // gpe_shard_setup has run
+    bool home = false;               // every particle sits on its owner, counts on the host, ghosts dropped
+    gpe_shard_layout layout;
+    uint32_t rank = 0;
+    float scale = 1.0f;              // capacity_scale of the neighbour segments
+    double planned_per_block = 0.0;  // block population the segments were sized for
+    uint8_t *d_owner = nullptr;      // library-owned device tables (gpe_shard_plan)
+    uint32_t *d_mask = nullptr;
+    uint64_t tables_cap = 0;         // blocks
+    uint32_t *d_send = nullptr, *d_recv = nullptr;
+    uint64_t send_cap = 0, recv_cap = 0;          // words allocated
+    // the neighbour exchange spelled as an all-to-all (word offsets / counts per rank; zero for non-neighbours)
+    uint64_t x_send_off[GPE_SHARD_MAX_RANKS] = {}, x_send_cnt[GPE_SHARD_MAX_RANKS] = {};
+    uint64_t x_recv_off[GPE_SHARD_MAX_RANKS] = {}, x_recv_cnt[GPE_SHARD_MAX_RANKS] = {};
+    uint32_t n_neighbours = 0;
+    gpe_shard_collectives coll;      // caller-supplied collectives
+    bool coll_set = false;
+    gpe_local_group *group = nullptr;   // local group this context is a rank of
+    uint32_t group_rank = 0;
+    uint32_t *d_small = nullptr;     // device scratch for the small host-side collectives (kCtlSmallWords)
+    uint32_t *d_hist = nullptr, *d_first = nullptr;   // re-sort: Morton-block histogram / first local index
+    uint64_t hist_cap = 0;
+    uint32_t *d_rows_send = nullptr, *d_rows_recv = nullptr;   // re-cut: particle rows on the move
+    uint64_t rows_send_cap = 0, rows_recv_cap = 0;
+    uint64_t resorts = 0, steps = 0, n_ghost = 0;
+    uint32_t recuts = 0;
+};
+constexpr uint64_t kCtlSmallWords = 4096;
+
 }  // namespace gpe
 
 struct gpe_ctx {
@@ -393,6 +425,7 @@ struct gpe_ctx {
     gpe::OnesweepWorkspace os_ws;
     gpe::NativeState native;
     gpe::ShardState shard;
+    gpe::ShardCtl ctl;
     bool use_onesweep = true;        // GPE_SORT=safe selects the reduce-then-scan sort
 
     // profiling
@@ -498,6 +531,22 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
 void native_release(gpe_ctx *c);
 void shard_release(gpe_ctx *c);
 void comm_release(gpe_ctx *c);
+void ctl_release(gpe_ctx *c);
+// collectives of a sharded run, carried by (in this order) the caller's callbacks, the local group, the RCCL communicator
+gpe_status coll_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op);
+gpe_status coll_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
+                               uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt);
+// the same over the RCCL communicator (gpe_comm.hip) and over a local group (gpe_group.hip)
+gpe_status rccl_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op);
+gpe_status rccl_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
+                               uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt);
+gpe_status group_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op);
+gpe_status group_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
+                                uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt);
+gpe_status group_exchange_segments(gpe_ctx *c);   // the per-step neighbour exchange, event-ordered (no stream sync)
+void group_leave(gpe_ctx *c);
+gpe_status resort_for_shard(gpe_ctx *c);          // ParticleSort::sort on the owned particles (gpe_api.hip do_resort)
+gpe_status shard_ensure_flag_capacity(gpe_ctx *c);
 std::string shard_error_text(uint32_t flags);
 gpe_status step_for_shard(gpe_ctx *c, float dt);           // one ordinary step (gpe_api.hip do_step)
 gpe_status grow_for_shard(gpe_ctx *c, uint64_t capacity);  // reallocate the particle buffers, keeping the first c->n

@@ -298,6 +298,8 @@ static gpe_status ensure_flag_capacity(gpe_ctx *c)
     return GPE_OK;
 }
 
+gpe_status shard_ensure_flag_capacity(gpe_ctx *c) { return ensure_flag_capacity(c); }
+
 static gpe_status launch_pack(gpe_ctx *c, bool reset_headers)
 {
     ShardState &S = c->shard;

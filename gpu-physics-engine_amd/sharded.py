@@ -20,17 +20,18 @@ single-device run performs: the sharded result is bit-identical (tests/test_shar
 ranks against the single-process oracle).  The Morton re-sort assigns the new indices globally: new index =
 (particles of all ranks in Morton blocks before mine) + rank inside the block by (cell key, old index).
 
-Device-resident exchange (default on GPUs, `ShardedState(..., device_exchange=True)`): the same protocol with
-the packing, hole filling and appending done by library kernels (csrc/k_shard.hip) on fixed-size neighbour
-segments, the particle counts kept on the device, and ONE `all_to_all_single` per step whose split sizes are
-zero for every rank that is not a neighbour (RCCL issues a send/recv pair per neighbour inside one group) --
-no host round trip per step.  The torch formulation below stays as the general path (any displacement, CPU
-tests) and as the specification the kernels are tested against.
+Device-resident path (default on GPUs, `ShardedState(..., device_exchange=True)`): the same protocol inside the
+library, control plane included -- packing, hole filling and appending by kernels on fixed-size neighbour segments, the
+particle counts kept on the device, the decomposition's tables, the cell-size agreement, the global re-sort and the
+re-cut behind `gpe_shard_setup` / `gpe_shard_run_scheduled` (csrc/gpe_shard_ctl.hip), so that a host in any language
+does what this file does with a handful of calls.  Here that path only chooses who carries the collectives: the
+library's own RCCL communicator, or callbacks into torch.distributed.  The torch formulation below stays as the general
+path (any displacement, CPU tests with a pluggable engine) and as the specification the kernels are tested against.
 
 Load balance: at re-sort steps the ranks compare their particle counts and, when they have drifted apart (a pile
 under gravity), re-cut the rectangles at the particle quantiles of the all-reduced block-column / block-row
-histograms and move the particles to their new owners (`ShardedState.rebalance`).  Buffers of a rank that fills
-up between re-sorts grow by themselves (library side, gpe_shard_step).
+histograms and move the particles to their new owners (`ShardedState.rebalance`; `gpe_shard_recut` in the library).
+Buffers of a rank that fills up between re-sorts grow by themselves (library side, gpe_shard_step).
 
 The engine behind a rank is pluggable (`engine` argument): `GpeEngine` drives libgpe.so on the rank's GPU;
 the CPU tests plug in an oracle-backed engine (tests only) to exercise this file without a GPU.
@@ -319,8 +320,13 @@ class GpeEngine:
 # the sharded state
 # ------------------------------------------------------------------------------------------------------
 class ShardedState:
-    """`State` for one rank of a sharded run.  `engine` holds this rank's owned particles (first n_owned
-    slots) and exposes torch views of its arrays; everything here is device-agnostic torch code."""
+    """`State` for one rank of a sharded run.  `engine` holds this rank's owned particles (first n_owned slots).
+
+    device_exchange (default on GPUs): everything is inside the library -- the decomposition's tables and segment
+    buffers, the cell-size agreement, the per-step exchange, the global re-sort and the re-cut (csrc/gpe_shard_ctl.hip,
+    `gpe_shard_setup` / `gpe_shard_run_scheduled`); this class only says who carries the collectives: the library's own
+    RCCL communicator (process group nccl), or callbacks into torch.distributed (gloo rehearsals on a one-GPU box,
+    staged through host memory).  Otherwise the torch formulation below runs (any displacement, CPU tests)."""
 
     def __init__(self, engine, dec, rank, group=None, device_exchange=None, rebalance=1.25):
         self.e, self.dec, self.rank, self.group = engine, dec, rank, group
@@ -328,9 +334,6 @@ class ShardedState:
         self.ws = dec.world_size
         self.n_owned = engine.n_owned
         self.n_ghost = 0
-        self._agree_on_cell_size()
-        self.tables = engine.make_tables(dec, max(1 << 16, engine.capacity() // 4))
-        engine.set_active_cells(dec.active_cells(rank))
         self.stats = {"migrants": 0, "ghosts": 0, "steps": 0}
         # gloo moves host tensors only: a GPU engine under a gloo group (tests on a one-GPU box) stages on the host;
         # with the nccl (= RCCL) backend the device buffers go straight to send/recv
@@ -341,16 +344,19 @@ class ShardedState:
             device_exchange = os.environ.get("GPE_SHARD_EXCHANGE", "device") != "torch"
         self.fast = bool(device_exchange and self.ws > 1 and isinstance(engine, GpeEngine) and
                          dec.min_region_blocks() >= 2 and len(dec.neighbours(rank)) <= 8)
-        self.fast_active = False
         self.transport = None
         if self.fast:
-            self._plan_device_exchange()
-            self._setup_transport()
+            self._setup_control_plane()
+        else:
+            self._agree_on_cell_size()
+            self.tables = engine.make_tables(dec, max(1 << 16, engine.capacity() // 4))
+            engine.set_active_cells(dec.active_cells(rank))
 
     def _agree_on_cell_size(self):
         """The cell size is 2.2 x the largest radius of the WHOLE system (grid.rs:159-161); a rank's context only
         saw its own particles.  Every rank takes the maximum over the ranks (Grid::new's max_obj_radius) and checks
-        that the decomposition was cut with that cell size -- a rank on a different grid would exchange nonsense."""
+        that the decomposition was cut with that cell size -- a rank on a different grid would exchange nonsense.
+        (The device-resident path does the same inside gpe_shard_setup.)"""
         e = self.e
         if not isinstance(e, GpeEngine):
             return
@@ -370,83 +376,31 @@ class ShardedState:
             raise ValueError("sharded run: the decomposition was cut with cell size %r, the system's is %r "
                              "(2.2 x the largest radius over all ranks)" % (float(self.dec.cell_size), float(cs.value)))
 
-    # -- device-resident exchange --------------------------------------------------------------------------
-    def _plan_device_exchange(self):
-        e, dec, rank = self.e, self.dec, self.rank
-        per_block = self._densest_rank_per_block()                          # particles per 8x8-cell block
-        self.planned_per_block = per_block
-
+    # -- the control plane inside the library ------------------------------------------------------------------
+    def _setup_control_plane(self):
+        e, dec = self.e, self.dec
+        lay = L.GpeShardLayout()
+        xc = (C.c_int32 * (dec.px + 1))(*dec.xcuts)
+        yc = (C.c_int32 * (dec.py + 1))(*dec.ycuts)
+        L.check(L.load().gpe_shard_layout_build(dec.world[0], dec.world[1], float(dec.cell_size), self.ws, dec.px, dec.py,
+                                                xc, yc, C.byref(lay)))
+        self._install_collectives()
         scale = float(os.environ.get("GPE_SHARD_CAP_SCALE", "1"))            # tests shrink the segments to see the error
+        try:
+            e.ctx.call("gpe_shard_setup", C.byref(lay), self.rank, scale)
+        except L.GpeError as exc:
+            self._raise_transport_error()
+            if "disagree on the segment sizes" in str(exc) or "cell size" in str(exc):
+                raise ValueError(str(exc)) from exc
+            raise
 
-        def caps(src, dst):
-            return dec.segment_caps(src, dst, per_block, scale)              # (migrant rows, ghost rows)
-
-        words = dec.segment_words
-
-        nb = dec.neighbours(rank)
-        plan = L.GpeShardPlan()
-        plan.struct_size = C.sizeof(L.GpeShardPlan)
-        plan.rank, plan.world_size, plan.n_slots = rank, self.ws, len(nb) + 1
-        plan.blocks_x, plan.blocks_y = dec.bx, dec.by
-        self.in_splits, self.out_splits = [0] * self.ws, [0] * self.ws
-        so = ro = 0
-        for s, p in enumerate(nb):
-            cm, cg = caps(rank, p)
-            plan.slot_rank[s], plan.send_off[s], plan.send_cap_mig[s], plan.send_cap_gho[s] = p, so, cm, cg
-            self.in_splits[p] = words(cm, cg)
-            so += words(cm, cg)
-            cm, cg = caps(p, rank)
-            plan.recv_off[s], plan.recv_cap_mig[s], plan.recv_cap_gho[s] = ro, cm, cg
-            self.out_splits[p] = words(cm, cg)
-            ro += words(cm, cg)
-        self.send_words, self.recv_words = so, ro
-        self._check_segment_agreement()
-        s = len(nb)                                                           # this rank's own segment: not sent
-        cg_self = sum(plan.send_cap_mig[i] for i in range(len(nb)))
-        plan.slot_rank[s], plan.send_off[s], plan.send_cap_mig[s], plan.send_cap_gho[s] = rank, so, 0, cg_self
-        plan.recv_off[s], plan.recv_cap_mig[s], plan.recv_cap_gho[s] = ro, 0, 0
-        self.send_buf = torch.zeros(so + words(0, cg_self) + 16, dtype=torch.int32, device=e.device)
-        self.recv_buf = torch.zeros(ro + 16, dtype=torch.int32, device=e.device)
-        owner_t, mask_t = self.tables[0], self.tables[1]
-        plan.d_owner_of_block, plan.d_dest_mask_of_block = owner_t.data_ptr(), mask_t.data_ptr()
-        plan.d_send, plan.d_recv = self.send_buf.data_ptr(), self.recv_buf.data_ptr()
-        torch.cuda.synchronize(e.device)
-        e.ctx.call("gpe_shard_configure", C.byref(plan))
-        self.plan = plan
-        if self.stage_cpu:
-            # pinned staging buffers: torch's host allocator records the stream they were used on -- the engine's
-            # stream is torch's own (GpeEngine.__init__), so that record stays valid past gpe_destroy
-            self.send_host = torch.zeros(so, dtype=torch.int32).pin_memory()
-            self.recv_host = torch.zeros(ro, dtype=torch.int32).pin_memory()
-
-    def _check_segment_agreement(self):
-        """Every segment a rank sends must be exactly as long as the peer expects it: a grouped ncclSend / ncclRecv
-        pair of different lengths does not fail, it waits.  Both sides compute the capacities from the same inputs
-        (the decomposition, the all-reduced block densities), so this can only trip on a configuration that differs
-        between the ranks (an environment variable, a library version) -- raise on every rank instead of hanging."""
-        if self.ws <= 1:
-            return
-        mine = torch.tensor(self.in_splits, dtype=torch.int64)              # words this rank sends to each rank
-        dev = self.e.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-        rows = [torch.zeros(self.ws, dtype=torch.int64, device=dev) for _ in range(self.ws)]
-        dist.all_gather(rows, mine.to(dev), group=self.group)
-        sent_to_me = [int(rows[p][self.rank].item()) for p in range(self.ws)]
-        bad = [(p, sent_to_me[p], self.out_splits[p]) for p in range(self.ws) if sent_to_me[p] != self.out_splits[p]]
-        flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        if int(flag.item()):
-            raise ValueError("sharded run: rank %d and its neighbours disagree on the segment sizes (peer, words it "
-                             "sends, words expected): %s -- the ranks were configured differently" % (self.rank, bad or "none here"))
-
-    def _setup_transport(self):
-        """Who moves the packed segments between the ranks (gpe_shard_exchange, called by gpe_shard_run):
+    def _install_collectives(self):
+        """Who carries the control plane's collectives and the per-step segment exchange:
         "rccl"  -- the library itself: a communicator of its own (gpe_shard_comm_init; the 128-byte id travels over
-                   torch.distributed once), one grouped ncclSend / ncclRecv pair per neighbour on the context's
-                   stream.  The step loop then has no Python in it.  Default when the process group is nccl.
-        "torch" -- a callback into _move_segments (all_to_all_single, or isend / irecv with GPE_SHARD_P2P=1): gloo
+                   torch.distributed once).  The whole run then has no Python in it.  Default when the process group is nccl.
+        "torch" -- gpe_shard_set_collectives with callbacks into torch.distributed (all_reduce / all_to_all_single): gloo
                    rehearsals on a one-GPU box, staged through host memory.
-        A transport that cannot be set up (every rank sees the same error) leaves the run on the next one, and
-        finally on the torch exchange, instead of failing in step 1."""
+        A communicator that cannot be set up (every rank sees the same verdict) leaves the run on the callbacks."""
         import sys
         e = self.e
         want = os.environ.get("GPE_SHARD_TRANSPORT",
@@ -469,10 +423,9 @@ class ShardedState:
                     raise RuntimeError("rank 0 could not create an RCCL id: %s" % (L.load().gpe_last_error(None) or b"").decode())
                 raw = (C.c_uint8 * L.COMM_ID_BYTES)(*ident.tolist())
                 torch.cuda.synchronize(e.device)
-                # The choice of transport must be the SAME on every rank (a rank that left for the torch exchange while
-                # its peers sit in ncclRecv would hang the job at the first step): every rank reports how its own
-                # communicator set-up went, and the minimum decides.  (Both ends of a neighbour pair size their segments
-                # from the same all-reduced numbers, _plan_device_exchange, so the send / recv counts match by construction.)
+                # The choice must be the SAME on every rank (a rank that left for the callbacks while its peers sit in
+                # ncclRecv would hang the job at the first step): every rank reports how its own communicator set-up
+                # went, and the minimum decides.
                 ok, why = 1, None
                 try:
                     e.ctx.call("gpe_shard_comm_init", raw, self.rank, self.ws)      # collective
@@ -490,102 +443,92 @@ class ShardedState:
                     pass
                 raise RuntimeError("a rank could not set the communicator up" + (": %s" % why if why else " (not this one)"))
             except Exception as exc:                                   # noqa: BLE001 -- any backend error
-                print("[gpe sharded] in-library RCCL transport unavailable (%s: %s); moving the segments with "
+                print("[gpe sharded] in-library RCCL transport unavailable (%s: %s); carrying the collectives with "
                       "torch.distributed" % (type(exc).__name__, exc), file=sys.stderr, flush=True)
-        try:
-            self._move_segments()                      # rehearse once on the zeroed buffers
-            torch.cuda.synchronize(e.device)
-            self._transport_error = None
-            self._transport_cb = L.SHARD_TRANSPORT_FN(self._transport)   # keep the thunk alive
-            e.ctx.call("gpe_shard_set_transport", self._transport_cb, None)
-            self.transport = "torch"
-        except Exception as exc:                                       # noqa: BLE001
-            print("[gpe sharded] device-resident exchange disabled (%s: %s); using the torch exchange"
-                  % (type(exc).__name__, exc), file=sys.stderr, flush=True)
-            self.fast = False
+        self._transport_error = None
+        coll = L.GpeShardCollectives()
+        coll.struct_size = C.sizeof(L.GpeShardCollectives)
+        self._cb = (L.ALL_REDUCE_FN(self._cb_all_reduce), L.ALL_TO_ALL_FN(self._cb_all_to_all))   # keep the thunks alive
+        coll.all_reduce_u32, coll.all_to_all_u32 = self._cb
+        e.ctx.call("gpe_shard_set_collectives", C.byref(coll))
+        self.transport = "torch"
 
-    def _transport(self, user, d_send, d_recv, stream):
-        """gpe_shard_transport_fn: the library asks for the packed segments to be moved (d_send / d_recv are the
-        buffers of the plan, i.e. self.send_buf / self.recv_buf)."""
+    def _dev_words(self, ptr, count):
+        return torch.as_tensor(_DevArray(ptr, (int(count),), "<i4"), device=self.e.device)
+
+    def _cb_all_reduce(self, user, d_buf, count, op, stream):
+        """gpe_shard_collectives.all_reduce_u32 over torch.distributed (u32 words travel as int32: a sum wraps the same
+        way; a maximum is taken on the values read as unsigned)."""
         try:
-            self._move_segments()
+            with self.e.stream_ctx():
+                buf = self._dev_words(d_buf, count)
+                comm_cpu = self.stage_cpu or dist.get_backend(self.group) != "nccl"
+                t = buf.cpu() if comm_cpu else buf
+                if op == L.REDUCE_MAX:
+                    w = t.to(torch.int64) & 0xFFFFFFFF
+                    dist.all_reduce(w, op=dist.ReduceOp.MAX, group=self.group)
+                    t = w.to(torch.int32)               # (values above 2^31 wrap into the negative half: the same bits)
+                else:
+                    dist.all_reduce(t, group=self.group)
+                buf.copy_(t)
+                self.e.stream.synchronize()
             return 0
         except Exception as exc:                                       # noqa: BLE001 -- must not unwind into C
             self._transport_error = exc
             return 1
 
-    def _densest_rank_per_block(self):
-        """Particles per owned block on the most crowded rank (a collective: every rank gets the same number, so
-        both ends of every neighbour pair size their segments alike)."""
-        x0, y0, x1, y1 = self.dec.rect_blocks(self.rank)
-        d = torch.tensor([self.n_owned / float(max(1, (x1 - x0) * (y1 - y0)))], dtype=torch.float64)
-        if self.ws > 1:
-            if dist.get_backend(self.group) == "nccl":
-                d = d.to(self.e.device)
-            dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
-        return float(d.item())
-
-    def _move_segments(self):
-        """The neighbour segments packed by the library go to their ranks: one grouped send/recv per neighbour
-        (all_to_all_single with zero-sized splits for every other rank), enqueued on the library's stream."""
-        with self.e.stream_ctx():
-            send, recv = self.send_buf[:self.send_words], self.recv_buf[:self.recv_words]
-            if self.stage_cpu:                   # gloo rehearsal on a shared GPU: through host memory
-                self.send_host.copy_(send)
-                self.e.stream.synchronize()
-                send, recv = self.send_host, self.recv_host
-            if os.environ.get("GPE_SHARD_P2P") == "1":
-                # the same transfers spelled as explicit point-to-point operations (one isend + one irecv per
-                # neighbour in one batch = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd)
-                ops, so, ro = [], 0, 0
-                for p in range(self.ws):
-                    if self.in_splits[p]:
-                        ops.append(dist.P2POp(dist.isend, send[so:so + self.in_splits[p]], p, group=self.group))
-                        so += self.in_splits[p]
-                    if self.out_splits[p]:
-                        ops.append(dist.P2POp(dist.irecv, recv[ro:ro + self.out_splits[p]], p, group=self.group))
-                        ro += self.out_splits[p]
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            else:
-                dist.all_to_all_single(recv, send, self.out_splits, self.in_splits, group=self.group)
-            if self.stage_cpu:
-                self.recv_buf[:self.recv_words].copy_(self.recv_host)
-
-    def _fast_update(self, dt, resort, steps=1):
-        """[re-sort, re-cut] + `steps` ordinary steps (the first of them is the re-sort step's own)."""
-        e = self.e
-        if resort:
-            # every particle must sit on its owner before the global indices are assigned
-            if not self.fast_active:
-                e.set_counts(self.n_owned, self.n_owned)
-                e.ctx.call("gpe_shard_begin")
-            e.ctx.call("gpe_shard_exchange")
-            e.ctx.call("gpe_shard_unpack")
-            self.n_owned, _ = e.shard_counts(leave=True)                  # host sync: re-sort steps only
-            e.n_owned = self.n_owned
-            self.fast_active = False
-            e.set_counts(self.n_owned, self.n_owned)
-            recut = self.rebalance()                                      # collective; re-plans the segments itself
-            self.resort()
-            # the scene may have piled up on some ranks since the segments were sized: re-plan (collectively)
-            if not recut and self._densest_rank_per_block() > 1.5 * self.planned_per_block:
-                self._plan_device_exchange()
-        if not self.fast_active:
-            e.set_counts(self.n_owned, self.n_owned)
-            e.ctx.call("gpe_shard_begin")
-            self.fast_active = True
-        self._run_steps(dt, steps)
-
-    def _run_steps(self, dt, steps):
-        """`steps` ordinary steps inside the library: exchange (RCCL or the transport callback), unpack, step, pack."""
+    def _cb_all_to_all(self, user, d_send, send_off, send_cnt, d_recv, recv_off, recv_cnt, stream):
+        """gpe_shard_collectives.all_to_all_u32: one all_to_all_single (RCCL: a send / recv pair per peer in one group)."""
         try:
-            self.e.ctx.call("gpe_shard_run", float(dt), int(steps))
+            ws = self.ws
+            so, sc = [int(send_off[p]) for p in range(ws)], [int(send_cnt[p]) for p in range(ws)]
+            ro, rc = [int(recv_off[p]) for p in range(ws)], [int(recv_cnt[p]) for p in range(ws)]
+            with self.e.stream_ctx():
+                comm_cpu = self.stage_cpu or dist.get_backend(self.group) != "nccl"
+                dev = torch.device("cpu") if comm_cpu else self.e.device
+                send = self._dev_words(d_send, max(1, max(o + n for o, n in zip(so, sc))))
+                recv = self._dev_words(d_recv, max(1, max(o + n for o, n in zip(ro, rc))))
+                # all_to_all_single wants the pieces back to back in rank order
+                pieces = [send[so[p]:so[p] + sc[p]] for p in range(ws)]
+                flat = torch.cat(pieces).to(dev) if sum(sc) else torch.empty(0, dtype=torch.int32, device=dev)
+                got = torch.empty(sum(rc), dtype=torch.int32, device=dev)
+                if comm_cpu:
+                    self.e.stream.synchronize()
+                dist.all_to_all_single(got, flat, rc, sc, group=self.group)
+                o = 0
+                for p in range(ws):
+                    if rc[p]:
+                        recv[ro[p]:ro[p] + rc[p]].copy_(got[o:o + rc[p]])
+                    o += rc[p]
+                self.e.stream.synchronize()
+            return 0
+        except Exception as exc:                                       # noqa: BLE001 -- must not unwind into C
+            self._transport_error = exc
+            return 1
+
+    def _raise_transport_error(self):
+        exc = getattr(self, "_transport_error", None)
+        if exc is not None:
+            self._transport_error = None
+            raise exc
+
+    def _shard_stats(self):
+        st = L.GpeShardStats()
+        st.struct_size = C.sizeof(L.GpeShardStats)
+        self.e.ctx.call("gpe_shard_get_stats", C.byref(st))
+        return st
+
+    def _run_scheduled(self, dt, steps, resort_every, resort_first):
+        """State::update `steps` times inside the library: re-sorts (with re-cut) where the schedule says, gpe_shard_run
+        in between."""
+        try:
+            self.e.ctx.call("gpe_shard_run_scheduled", float(dt), int(steps), int(resort_every), 1 if resort_first else 0)
         except L.GpeError:
-            if getattr(self, "_transport_error", None) is not None:
-                exc, self._transport_error = self._transport_error, None
-                raise exc
+            self._raise_transport_error()
             raise
+        st = self._shard_stats()
+        self.stats["recuts"] = int(st.recuts)
+        self.n_owned = self.e.n_owned = int(st.n_owned)
 
     # -- helpers -------------------------------------------------------------------------------------
     def _ensure_capacity(self, need):
@@ -799,8 +742,6 @@ class ShardedState:
         self.dec = new
         self.tables = e.make_tables(new, max(1 << 16, e.capacity() // 4))
         e.set_active_cells(new.active_cells(rank))
-        if self.fast:
-            self._plan_device_exchange()
         self.stats["recuts"] = self.stats.get("recuts", 0) + 1
         return True
 
@@ -836,7 +777,7 @@ class ShardedState:
     def update(self, dt, resort=False):
         """state.rs:115-131 for one rank: [re-sort] -> exchange -> collide (owned + ghosts) -> integrate owned."""
         if self.fast:
-            self._fast_update(dt, resort)
+            self._run_scheduled(dt, 1, 0, resort)
             self.stats["steps"] += 1
             return
         if resort:
@@ -855,25 +796,28 @@ class ShardedState:
 
     def run(self, dt, steps, resort_every=0, resort_first=True):
         """state.rs:115-131 `steps` times; re-sorts on the first step (resort_first) and every resort_every steps.
-        With the device-resident exchange all steps between two re-sorts are ONE library call (gpe_shard_run)."""
-        s = 0
-        while s < steps:
-            resort = bool((s == 0 and resort_first) or (resort_every and s > 0 and s % resort_every == 0))
-            if not self.fast:
-                self.update(dt, resort=resort)
-                s += 1
-                continue
-            nxt = steps if not resort_every else min(steps, (s // resort_every + 1) * resort_every)
-            self._fast_update(dt, resort, steps=nxt - s)
-            self.stats["steps"] += nxt - s
-            s = nxt
+        With the device-resident exchange the whole schedule is ONE library call (gpe_shard_run_scheduled)."""
+        if self.fast:
+            self._run_scheduled(dt, steps, resort_every, resort_first)
+            self.stats["steps"] += steps
+            return
+        for s in range(steps):
+            self.update(dt, resort=bool((s == 0 and resort_first) or (resort_every and s > 0 and s % resort_every == 0)))
 
     def owned(self):
         """(gid, pos, prev) of the owned particles as host arrays."""
+        if self.fast:
+            cap = self.e.capacity()
+            gid = np.empty(cap, np.uint32)
+            pos, prev = np.empty((cap, 2), np.float32), np.empty((cap, 2), np.float32)
+            no = C.c_uint64()
+            self.e.ctx.call("gpe_shard_download_owned", gid.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
+                            prev.ctypes.data_as(C.c_void_p), cap, C.byref(no))
+            n = int(no.value)
+            self.n_owned = self.e.n_owned = n
+            self.n_ghost = int(self._shard_stats().n_ghost)
+            return gid[:n].astype(np.int64), pos[:n].copy(), prev[:n].copy()
         self.e.sync()
-        if self.fast and self.fast_active:
-            self.n_owned, n_total = self.e.shard_counts()                 # the counts live on the device
-            self.n_ghost = n_total - self.n_owned
         with self.e.stream_ctx():
             a = self.e.arrays()
             n = self.n_owned

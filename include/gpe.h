@@ -311,6 +311,112 @@ gpe_status gpe_shard_run(gpe_ctx *ctx, float dt, uint64_t steps);
 /* Do librccl.so.1 and every entry point used above resolve on this machine?  (No GPU needed.) */
 gpe_status gpe_comm_probe(void);
 
+/* ---- sharded control plane: decomposition, set-up, global re-sort, load re-cut, the scheduled run -----------------
+ * Everything a host needs to drive a sharded run through this header alone (no Python, no torch): the reference's
+ * State::update schedule (state.rs:115-131: re-sort gate, then the step) across ranks.  One context per rank -- one
+ * process per GPU, or one thread per context inside one process (gpe_local_group_*).  The collective calls below
+ * (marked so) must be made by every rank, in the same order. */
+#define GPE_SHARD_MAX_RANKS 26u
+/* The world cut into px x py rectangles of 8x8-cell blocks (rank = j * px + i owns block columns xcuts[i]..xcuts[i+1],
+ * block rows ycuts[j]..ycuts[j+1]).  A plain value: every rank builds the same one from the same arguments. */
+typedef struct gpe_shard_layout {
+    uint32_t struct_size;                       /* = sizeof(gpe_shard_layout)                                  */
+    uint32_t world_size, px, py;
+    float    world_width, world_height, cell_size;
+    int32_t  cells_x, cells_y;                  /* home cell columns / rows: floor(world / cell) + 1           */
+    int32_t  blocks_x, blocks_y;                /* 8x8-cell blocks                                             */
+    int32_t  xcuts[27];                         /* px + 1 entries rising from 0 to blocks_x (27 = MAX_RANKS + 1) */
+    int32_t  ycuts[27];                         /* py + 1 entries rising from 0 to blocks_y                    */
+} gpe_shard_layout;
+/* Host only (no GPU needed).  px = py = 0: the process grid as square as possible, px <= py.  xcuts / ycuts NULL: equal
+ * widths; else px + 1 / py + 1 entries (what gpe_shard_recut derives from the particle quantiles). */
+gpe_status gpe_shard_layout_build(float world_width, float world_height, float cell_size, uint32_t world_size,
+                                  uint32_t px, uint32_t py, const int32_t *xcuts, const int32_t *ycuts,
+                                  gpe_shard_layout *out);
+/* Owner rank of each of n host positions (interleaved x,y; the kernels' own f32 arithmetic: floor(p / cell) >> 3,
+ * clamped to the block grid): how a host deals the initial particles to the ranks. */
+gpe_status gpe_shard_layout_owner_of(const gpe_shard_layout *layout, const float *pos_xy, uint64_t n, uint8_t *owner_out);
+/* Cut `bins` block columns (rows) into `parts` runs of about equal particle count, every run at least min_width blocks
+ * wide: cuts_out receives parts + 1 entries.  Pure function (every rank derives the same cuts from the same histogram). */
+gpe_status gpe_shard_quantile_cuts(const uint64_t *hist, uint32_t bins, uint32_t parts, uint32_t min_width, int32_t *cuts_out);
+
+/* What the control plane needs from "the other ranks", when it is not the in-library RCCL communicator
+ * (gpe_shard_comm_init / _attach) or a local group (gpe_local_group_join): two collectives over device memory, both
+ * ordered with hip_stream; they may block the host.  Return 0 on success. */
+enum { GPE_REDUCE_SUM = 0, GPE_REDUCE_MAX = 1 };
+typedef struct gpe_shard_collectives {
+    uint32_t struct_size;
+    uint32_t reserved;
+    void *user;
+    /* in-place all-reduce of `count` u32 words at d_buf over all ranks (op: GPE_REDUCE_*) */
+    int32_t (*all_reduce_u32)(void *user, uint32_t *d_buf, uint64_t count, uint32_t op, void *hip_stream);
+    /* for every rank r: send_count[r] words at d_send + send_off[r] go to rank r, which finds them at its d_recv +
+     * recv_off[this rank]; recv_count[r] words arrive from rank r.  (ncclSend / ncclRecv pairs in one group.) */
+    int32_t (*all_to_all_u32)(void *user, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_count,
+                              uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_count, void *hip_stream);
+} gpe_shard_collectives;
+/* NULL: back to the in-library communicator.  The struct is copied. */
+gpe_status gpe_shard_set_collectives(gpe_ctx *ctx, const gpe_shard_collectives *coll);
+
+/* Several contexts of ONE process as the ranks of a sharded run: one host thread per context (every collective call
+ * blocks until all ranks have made it), segments and collectives moved by hipMemcpyAsync / kernels between the
+ * contexts' buffers (same device, or peers).  What a single-process host -- the reference's State owns one device,
+ * renderer/wgpu_context.rs:42-49 -- grows into on a multi-GPU node without a collective library. */
+typedef struct gpe_local_group gpe_local_group;
+gpe_status gpe_local_group_create(uint32_t world_size, gpe_local_group **out);
+gpe_status gpe_local_group_destroy(gpe_local_group *group);
+/* The context becomes rank `rank` of the group: its collectives and its segment transport are the group's. */
+gpe_status gpe_local_group_join(gpe_ctx *ctx, gpe_local_group *group, uint32_t rank);
+/* A rank that failed leaves the others waiting in a collective: this wakes them all with an error. */
+gpe_status gpe_local_group_abort(gpe_local_group *group);
+
+/* ParticleSystem::new_from_buffers (particle_system.rs:49-99) for one rank: its n owned particles with their global
+ * indices (order_key[i] = the particle's index in the unsharded system), buffers sized for `capacity` particles
+ * (0: 1.3 n + 4096; ghosts and arrivals need room).  prev_xy NULL: previous = current. */
+gpe_status gpe_shard_set_particles(gpe_ctx *ctx, const float *pos_xy, const float *prev_xy, const float *radius,
+                                   const uint32_t *order_key, uint64_t n, uint64_t capacity);
+/* COLLECTIVE.  Makes the context rank `rank` of `layout`: agrees on the cell size of the whole system (2.2 x the
+ * largest radius over all ranks, grid.rs:159-161) and checks the layout was cut with it, switches the order keys on,
+ * cuts the tile grid to the rank's rectangle + ghost ring, sizes the neighbour segments from the densest rank's block
+ * population x capacity_scale (1.0; both ends of a pair get the same numbers, and the set-up compares them: a send and
+ * a receive of different lengths would wait for ever), allocates the tables and segment buffers inside the library and
+ * configures the device-resident exchange (gpe_shard_configure).  Needs collectives: a communicator, a local group or
+ * gpe_shard_set_collectives; every rectangle at least two blocks wide, at most 8 neighbours. */
+gpe_status gpe_shard_setup(gpe_ctx *ctx, const gpe_shard_layout *layout, uint32_t rank, float capacity_scale);
+/* The layout in use (gpe_shard_recut replaces it). */
+gpe_status gpe_shard_get_layout(const gpe_ctx *ctx, gpe_shard_layout *out);
+/* COLLECTIVE.  ParticleSort::sort (particle_sort.rs:58-69) across the ranks: every particle goes home to its owner
+ * (exchange + unpack, ghosts dropped), then K1 + stable sort by home-cell key + K4 on the owned particles in the order
+ * of their old global indices, and the NEW global indices -- the particle's position in the single-device sorted order --
+ * from one all-reduce of the histogram over Morton blocks (a block of 64 consecutive keys = one 8x8-cell block = one
+ * owner): index = particles of all ranks in earlier blocks + position inside the block.  Leaves the context with
+ * host-side counts; the next gpe_shard_run_scheduled / gpe_shard_begin starts the device-resident loop again. */
+gpe_status gpe_shard_resort(gpe_ctx *ctx);
+/* COLLECTIVE; call where gpe_shard_resort may be called (it is called BY gpe_shard_run_scheduled before its re-sorts).
+ * When the most loaded rank owns more than `above` x the mean (1.25; <= 0: never): new cuts at the particle quantiles of
+ * the all-reduced block-column / block-row histograms, every particle moved to its new owner (one all-to-all), tables,
+ * tile grid and segments re-planned.  Results do not depend on the cuts.  *recut (may be NULL) = 1 when they changed. */
+gpe_status gpe_shard_recut(gpe_ctx *ctx, float above, int32_t *recut);
+/* COLLECTIVE.  State::update (state.rs:115-131) `steps` times for this rank: a re-sort (gpe_shard_recut at 1.25, then
+ * gpe_shard_resort) before step 0 when resort_first != 0 and before every resort_every-th step (0: never), and
+ * gpe_shard_run for the steps in between -- no host synchronisation except at the re-sorts. */
+gpe_status gpe_shard_run_scheduled(gpe_ctx *ctx, float dt, uint64_t steps, uint64_t resort_every, int32_t resort_first);
+/* The rank's owned particles as host arrays (synchronises; the counts come from the device): up to `capacity` of
+ * them, *n_owned receives their number.  order_key_out / pos_xy_out / prev_xy_out may each be NULL. */
+gpe_status gpe_shard_download_owned(gpe_ctx *ctx, uint32_t *order_key_out, float *pos_xy_out, float *prev_xy_out,
+                                    uint64_t capacity, uint64_t *n_owned);
+/* Counters of the control plane since gpe_shard_setup. */
+typedef struct gpe_shard_stats {
+    uint32_t struct_size;
+    uint32_t recuts;             /* gpe_shard_recut calls that changed the cuts                          */
+    uint64_t resorts;            /* gpe_shard_resort calls                                               */
+    uint64_t steps;              /* steps run by gpe_shard_run_scheduled                                 */
+    uint64_t n_owned, n_ghost;   /* as of the last synchronising call                                    */
+    uint32_t n_neighbours;
+    uint32_t transport;          /* 0 none, 1 RCCL inside the library, 2 local group, 3 caller callbacks */
+} gpe_shard_stats;
+gpe_status gpe_shard_get_stats(gpe_ctx *ctx, gpe_shard_stats *out);
+
 /* ---- profiling (wgpu_profiler scopes threaded through every reference call) ------------------ */
 typedef struct gpe_timing {
     char     name[64];    /* the reference's scope label, e.g. "Sort map" (grid.rs:329); kernel-level

@@ -50,3 +50,39 @@ def test_cpp_reference_tests_pass_on_gpu(gpe):
     assert r.returncode == 0, r.stdout + r.stderr
     for n in REFERENCE_TEST_NAMES:
         assert "test %s ... ok" % n in r.stdout
+
+
+SHARD_SRC = os.path.join(ROOT, "tests", "cpp", "sharded_two_contexts.cpp")
+SHARD_EXE = os.path.join(ROOT, "tests", "cpp", "sharded_two_contexts")
+SHARD_TESTS = ["two_contexts_local_group_equal_one_context", "two_contexts_caller_collectives_equal_one_context",
+               "four_contexts_local_group_equal_one_context"]
+
+
+def _build_sharded(gpe):
+    gpe.build()
+    deps = [SHARD_SRC, os.path.join(ROOT, "include", "gpe.h")]
+    if not os.path.exists(SHARD_EXE) or any(os.path.getmtime(d) > os.path.getmtime(SHARD_EXE) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", SHARD_SRC, "-L" + LIBDIR, "-lgpe",
+                               "-Wl,-rpath," + LIBDIR, "-o", SHARD_EXE])
+    return SHARD_EXE
+
+
+def test_cpp_sharded_host_compiles_against_the_header_alone(gpe):
+    """tests/cpp/sharded_two_contexts.cpp includes include/gpe.h and nothing else of ours: no Python, no torch, no HIP
+    header -- the sharded run's control plane is behind the C-ABI."""
+    exe = _build_sharded(gpe)
+    assert subprocess.check_output([exe, "--list"], text=True).split() == SHARD_TESTS
+    src = open(SHARD_SRC).read()
+    assert "hip/" not in src and "torch" not in src.replace("no torch", "")
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_host_equals_one_context_on_gpu(gpe):
+    """Several gpe_ctx in one process (a thread each) through 30 steps with two re-sorts, over the library's local group
+    and over the host's own collectives: bit-identical to one context."""
+    exe = _build_sharded(gpe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for n in SHARD_TESTS:
+        assert "test %s ... ok" % n in r.stdout

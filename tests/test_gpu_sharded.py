@@ -559,3 +559,110 @@ def test_migrants_into_a_spill_window_on_a_step_that_keeps_its_table(gpe, tmp_pa
     order = np.argsort(gid)
     assert np.array_equal(np.concatenate(poss)[order], want_pos)
     assert np.array_equal(np.concatenate(prevs)[order], want_prev)
+
+
+@pytest.mark.parametrize("ws,n,world,gravity", [
+    (2, 40_000, (420.0, 300.0), (40.0, 0.0)),
+    (4, 60_000, (500.0, 380.0), (25.0, -30.0)),
+    (8, 120_000, (700.0, 520.0), (15.0, -20.0)),
+    (2, 40_000, (420.0, 300.0), (0.0, -80.0)),      # everything falls onto rank 0: buffers grow, the rectangles are re-cut
+])
+def test_local_group_in_one_process_equals_single_context(gpe, ws, n, world, gravity):
+    """The sharded run with NO Python in its control plane and no torch anywhere: `ws` contexts of this process, one
+    thread each, as a local group (gpe_local_group_*), set up and stepped by gpe_shard_setup / gpe_shard_run_scheduled
+    (decomposition, cell size, segments, global re-sort, re-cut: csrc/gpe_shard_ctl.hip).  Bit-identical to the
+    single-context run; the order keys a rank hands back ARE the single-context indices."""
+    lg = importlib.import_module("gpu-physics-engine_amd.local_group")
+    steps, dt, seed, every = 14, 0.05, 5, 6
+    if gravity[1] <= -80.0:
+        steps, every = 30, 17
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
+    run = lg.LocalShardedRun(pos, rad, world, ws, gravity=gravity)
+    run.run(dt, steps, resort_every=every, resort_first=True)
+    owned = run.owned()
+    stats = run.stats()
+    run.close()
+    ref = gpe.State(pos, rad, world=world, gravity=gravity, mode=gpe.MODE_NATIVE)
+    ref.run(dt, steps, resort_every=every, resort_first=True)
+    want_pos, want_prev = ref.positions(), ref.previous_positions()
+    ref.close()
+    seen = np.zeros(n, bool)
+    for r, (gid, p, q) in enumerate(owned):
+        assert not seen[gid].any()
+        seen[gid] = True
+        assert np.array_equal(p, want_pos[gid]), "rank %d positions" % r
+        assert np.array_equal(q, want_prev[gid]), "rank %d previous positions" % r
+        assert stats[r]["transport"] == 2 and stats[r]["steps"] == steps and stats[r]["resorts"] == (steps + every - 1) // every
+    assert seen.all()
+    if gravity[1] <= -80.0:
+        assert all(s["recuts"] >= 1 for s in stats), stats
+
+
+def test_config4_workload_800m_single_context_and_eight_ranks(gpe):
+    """BASELINE.json configs[4]'s WORKLOAD on the one GPU of the box: 800 M particles at the reference density in the
+    near-square world (45 953 cells per axis: the regime the 16-bit cell coordinates of grid.wgsl:101-114 cap, 33 M
+    blocks, the FOUR-pass block-key sort no smaller case reaches), gravity on, two steps with the first re-sorting.
+    (a) one NATIVE context: four radix passes, the re-sort is a permutation, positions finite and inside the walls;
+    (b) eight ranks x 100 M in one process (a local group sharing cuda:0; the box allows six GPU processes), run after
+        (a) is closed: bit-identical to (a).  No xGMI is involved -- that is the driver's SCALE run."""
+    import ctypes as C
+    import torch
+    n, ws = 800_000_000, 8
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 150 << 30:
+        pytest.skip("needs ~110 GB of device memory for the single context (free: %d GB)" % (free >> 30))
+    try:
+        avail_kb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1])
+    except Exception:                                      # noqa: BLE001
+        avail_kb = 0
+    if avail_kb and avail_kb < 90 << 20:
+        pytest.skip("needs ~70 GB of host memory (available: %d GB)" % (avail_kb >> 20))
+    lg = importlib.import_module("gpu-physics-engine_amd.local_group")
+    world = gpe.scenes.world_for(n, aspect=1.0)
+    assert 50_000 < world[0] < 51_000 and world[0] == world[1], world
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED + 4)
+    g, dt, steps = (0.0, -9.81), 1 / 60, 2
+    # (a)
+    ref = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_NATIVE)
+    info = ref.ctx.pipeline_info()
+    assert (info["pipeline"], info["sort_passes"]) == (gpe._lib.PIPELINE_NATIVE, 4), info
+    ref.run(dt, steps, resort_every=0, resort_first=True)
+    want_pos, want_prev = ref.positions(), ref.previous_positions()
+    ids = ref.particles.download_particle_ids()
+    info = ref.ctx.pipeline_info()
+    ref.close()
+    assert info["native_steps"] == steps and info["compat_steps"] == 0, info
+    seen = np.zeros(n, bool)
+    seen[ids] = True
+    assert seen.all(), "the re-sort is not a permutation"
+    del ids
+    assert np.isfinite(want_pos).all()
+    assert want_pos.min() >= 0.5 and want_pos[:, 0].max() <= np.float32(world[0]) - np.float32(0.5) and \
+        want_pos[:, 1].max() <= np.float32(world[1]) - np.float32(0.5)
+    cells = int(np.floor(np.float32(world[0]) / (np.float32(0.5) * np.float32(2.2)))) + 1
+    assert 45_000 < cells < 47_000, cells
+    # (b)
+    run = lg.LocalShardedRun(pos, rad, world, ws, gravity=g)
+    del pos, rad
+    run.run(dt, steps, resort_every=0, resort_first=True)
+    seen[:] = False
+    stats = run.stats()
+    for r in range(ws):
+        c = run.ctx[r]
+        cap = C.c_uint64()
+        c.call("gpe_capacity", C.byref(cap))
+        gid, p, q = np.empty(cap.value, np.uint32), np.empty((cap.value, 2), np.float32), np.empty((cap.value, 2), np.float32)
+        no = C.c_uint64()
+        c.call("gpe_shard_download_owned", gid.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p),
+               q.ctypes.data_as(C.c_void_p), cap.value, C.byref(no))
+        k = int(no.value)
+        assert 90_000_000 < k < 110_000_000, (r, k)
+        gid = gid[:k].astype(np.int64)
+        assert not seen[gid].any()
+        seen[gid] = True
+        assert np.array_equal(p[:k], want_pos[gid]), "rank %d positions" % r
+        assert np.array_equal(q[:k], want_prev[gid]), "rank %d previous positions" % r
+        assert stats[r]["resorts"] == 1 and stats[r]["transport"] == 2, stats[r]
+        del gid, p, q
+    run.close()
+    assert seen.all()

@@ -107,7 +107,8 @@ def _rust_struct_fields(name):
 
 
 def test_repr_c_structs_match_the_header_field_for_field():
-    for name in ("gpe_config", "gpe_pipeline_info", "gpe_timing", "gpe_trace_event", "gpe_shard_plan"):
+    for name in ("gpe_config", "gpe_pipeline_info", "gpe_timing", "gpe_trace_event", "gpe_shard_plan", "gpe_shard_layout",
+                 "gpe_shard_stats"):
         assert _c_struct_fields(name) == _rust_struct_fields(name), name
 
 
