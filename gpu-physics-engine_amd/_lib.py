@@ -69,6 +69,7 @@ class GpeShardPlan(C.Structure):
         ("send_off", C.c_uint32 * 9), ("send_cap_mig", C.c_uint32 * 9), ("send_cap_gho", C.c_uint32 * 9),
         ("recv_off", C.c_uint32 * 9), ("recv_cap_mig", C.c_uint32 * 9), ("recv_cap_gho", C.c_uint32 * 9),
         ("d_send", C.c_void_p), ("d_recv", C.c_void_p),
+        ("own_x0", C.c_int32), ("own_y0", C.c_int32), ("own_x1", C.c_int32), ("own_y1", C.c_int32),
     ]
 
 

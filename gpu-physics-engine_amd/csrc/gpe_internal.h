@@ -317,7 +317,12 @@ struct NativeState {
 // Device-resident halo exchange of a sharded run (k_shard.hip): particle counts live on the device, the host
 // only keeps an upper bound.  Slots = the neighbouring ranks in ascending order, then this rank itself.
 constexpr int kShardMaxSlots = 9;
-constexpr int kShardOwned = 0, kShardTotal = 1, kShardError = 2, kShardEpoch = 3, kShardHoles = 4;   // counts[] words
+// counts[] words.  Two sets of them (kShardSetWords apart), alternating with every unpack: the unpack kernel reads the
+// old set in all its workgroups while one of them writes the new one.  The error word is sticky and shared: always
+// word kShardError of set 0.
+constexpr int kShardOwned = 0, kShardTotal = 1, kShardError = 2, kShardEpoch = 3, kShardHoles = 4;
+constexpr int kShardSetWords = 8;
+constexpr int kShardDoneTicket = 5;              // set 0: workgroups of the unpack launch that are through (the last one resets the send headers)
 struct ShardSlots {                  // passed to the kernels by value
     uint32_t n_slots;
     uint32_t rank[kShardMaxSlots];
@@ -325,19 +330,119 @@ struct ShardSlots {                  // passed to the kernels by value
     uint32_t recv_off[kShardMaxSlots], recv_cap_mig[kShardMaxSlots], recv_cap_gho[kShardMaxSlots];
     int8_t slot_of_rank[32];
 };
+constexpr uint32_t kShardErrSendOverflow = 1u;   // more rows for a neighbour than its segment takes
+constexpr uint32_t kShardErrNoSlot = 2u;         // a particle needs a rank that is not a neighbour (moved > 1 block)
+constexpr uint32_t kShardErrCapacity = 4u;       // owned + ghosts exceed the particle capacity
+constexpr uint32_t kShardErrHoles = 8u;          // more migrants in one step than the hole list takes
+constexpr uint32_t kShardErrRecvOverflow = 16u;  // a received header claims more rows than the segment holds
+constexpr int kSegHeader = 4;                    // words: [n_migrants, n_ghosts, 0, 0]
+constexpr int kMigWords = 6, kGhoWords = 4;      // migrant row: x y prev_x prev_y r key; ghost row: x y r key
+
+// rows of one (slot, kind): a wave-aggregated append; every lane of the wave must call it
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
+{
+    const uint64_t m = __ballot(want);
+    if (m == 0) return 0xFFFFFFFFu;
+    const int leader = (int)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return want ? base + popc_below_lane(m) : 0xFFFFFFFFu;
+}
+
+// What a particle's NEW position means for the neighbours (k_shard.hip, "pack"): the owner of its block takes it over
+// when that is another rank (a migrant: listed as a hole here), and every rank within one block of it gets a ghost copy.
+// Shared by the pack kernel (k_shard_pack: all owned particles, the first pack of a run) and by the tiles of the
+// native step, which pack their own particles as they write them back (k_native.hip: the pack kernel then never runs).
+struct PackArgs {
+    const uint8_t *owner = nullptr;              // gpe_shard_plan tables over the global block grid
+    const uint32_t *dest_mask = nullptr;
+    int32_t blocks_x = 0, blocks_y = 0;
+    uint32_t my_rank = 0;
+    uint32_t *send = nullptr, *counts = nullptr, *holes = nullptr;   // counts: the set in use (kShardOwned, kShardHoles)
+    uint32_t *err = nullptr;                     // the sticky error word
+    uint8_t *hole_flag = nullptr;
+    uint32_t holes_cap = 0;
+    // the tiles: only tiles that reach outside this cell box (the rank's rectangle shrunk by two blocks on every side
+    // that has a neighbour) can hold a particle the neighbours care about; the others check that none of theirs ended
+    // up outside the `safe` box (world units: the rectangle shrunk by one block + one cell) -- that would be a particle
+    // that crossed a whole block in one step, which the exchange does not cover (kShardErrNoSlot)
+    int32_t ring_x0 = 0, ring_y0 = 0, ring_x1 = 0, ring_y1 = 0;
+    float safe_x0 = 0.f, safe_y0 = 0.f, safe_x1 = 0.f, safe_y1 = 0.f;
+    uint32_t on = 0;
+    ShardSlots slots;
+};
+
+// mine: this lane holds an owned particle (local index i, new position p, previous position q).  Every lane of the
+// wave must call it (ballots).
+__device__ __forceinline__ void pack_particle(const PackArgs &P, const bool mine, const uint32_t i, const float2 p,
+                                              const float2 q, const float rad, const uint32_t key, const float cell_size)
+{
+    uint32_t gho = 0;
+    int mig = -1;
+    if (mine) {
+        int bx = cell_coord(p.x, cell_size) >> 3, by = cell_coord(p.y, cell_size) >> 3;
+        bx = min(max(bx, 0), P.blocks_x - 1);
+        by = min(max(by, 0), P.blocks_y - 1);
+        const uint32_t b = (uint32_t)by * (uint32_t)P.blocks_x + (uint32_t)bx;
+        const uint32_t owner = P.owner[b];
+        gho = P.dest_mask[b] & 0x03FFFFFFu;             // ranks within one block of b, its owner excluded
+        if (owner != P.my_rank) mig = (int)owner;       // b's owner takes the particle over
+    }
+    if (__ballot(gho != 0 || mig >= 0) == 0) return;    // interior wave
+    uint32_t err = 0;
+    {
+        const uint32_t h = wave_append(&P.counts[kShardHoles], mig >= 0);
+        if (mig >= 0) {
+            if (h < P.holes_cap) { P.holes[h] = i; P.hole_flag[i] = 1; } else err |= kShardErrHoles;
+            if (P.slots.slot_of_rank[mig & 31] < 0) err |= kShardErrNoSlot;
+        }
+    }
+    uint32_t served = 0;
+    for (uint32_t s = 0; s < P.slots.n_slots; ++s) {
+        const uint32_t rk = P.slots.rank[s];
+        uint32_t *seg = P.send + P.slots.send_off[s];
+        const bool wm = mig == (int)rk;
+        const bool wg = ((gho >> rk) & 1u) != 0;
+        served |= wg ? (1u << rk) : 0u;
+        const uint32_t rm = wave_append(seg + 0, wm);
+        if (wm) {
+            if (rm < P.slots.send_cap_mig[s]) {
+                uint32_t *row = seg + kSegHeader + (uint64_t)rm * kMigWords;
+                row[0] = __float_as_uint(p.x); row[1] = __float_as_uint(p.y);
+                row[2] = __float_as_uint(q.x); row[3] = __float_as_uint(q.y);
+                row[4] = __float_as_uint(rad); row[5] = key;
+            } else err |= kShardErrSendOverflow;
+        }
+        const uint32_t rg = wave_append(seg + 1, wg);
+        if (wg) {
+            if (rg < P.slots.send_cap_gho[s]) {
+                uint32_t *row = seg + kSegHeader + (uint64_t)P.slots.send_cap_mig[s] * kMigWords + (uint64_t)rg * kGhoWords;
+                row[0] = __float_as_uint(p.x); row[1] = __float_as_uint(p.y);
+                row[2] = __float_as_uint(rad); row[3] = key;
+            } else err |= kShardErrSendOverflow;
+        }
+    }
+    if (gho & ~served) err |= kShardErrNoSlot;
+    if (err) atomicOr(P.err, err);
+}
+
 struct ShardState {
     bool on = false;                 // gpe_shard_configure was called
     bool active = false;             // between gpe_shard_begin and gpe_shard_counts: counts are on the device
     bool packed = false;             // the send buffer holds this step's rows
+    bool have_rect = false;          // the plan told the rank's rectangle: the tiles of the step pack (no pack kernel)
+    int32_t rect[4] = {0, 0, 0, 0};  // own rectangle in blocks, half-open: x0, y0, x1, y1
     uint32_t my_rank = 0;
     int32_t blocks_x = 0, blocks_y = 0;          // global block grid of the decomposition
     const uint8_t *owner = nullptr;              // caller's device tables (gpe_shard_plan)
     const uint32_t *dest_mask = nullptr;
     uint32_t *send = nullptr, *recv = nullptr;   // caller's device buffers
     ShardSlots slots;
-    uint32_t *counts = nullptr;      // device, 16 words (kShard*)
+    uint32_t *counts = nullptr;      // device, two sets of kShardSetWords words (kShard*)
+    uint32_t parity = 0;             // the set in use: counts + parity * kShardSetWords (flips with every unpack)
+    uint32_t *counts_now() const { return counts + parity * kShardSetWords; }
     uint32_t *host_counts = nullptr; // pinned mirror written by the unpack kernel
-    uint32_t *plan = nullptr;        // device: per-slot destination offsets of the rows being unpacked
     uint32_t *holes = nullptr, *fill_src = nullptr, *fill_dst = nullptr;   // device, holes_cap each
     uint8_t *hole_flag = nullptr;    // device, one byte per particle slot
     uint64_t holes_cap = 0, flag_cap = 0;
@@ -532,6 +637,7 @@ void native_release(gpe_ctx *c);
 void shard_release(gpe_ctx *c);
 void comm_release(gpe_ctx *c);
 void ctl_release(gpe_ctx *c);
+void shard_pack_args(gpe_ctx *c, PackArgs *P);
 // collectives of a sharded run, carried by (in this order) the caller's callbacks, the local group, the RCCL communicator
 gpe_status coll_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op);
 gpe_status coll_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,

@@ -468,6 +468,11 @@ static gpe_status plan_exchange(gpe_ctx *c, bool new_layout)
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     plan.d_owner_of_block = T.d_owner; plan.d_dest_mask_of_block = T.d_mask;
     plan.d_send = T.d_send; plan.d_recv = T.d_recv;
+    {
+        int x0, y0, x1, y1;
+        rect_blocks(L, rank, x0, y0, x1, y1);
+        plan.own_x0 = x0; plan.own_y0 = y0; plan.own_x1 = x1; plan.own_y1 = y1;
+    }
     if (new_layout) {
         int32_t box[4];
         active_cells(L, rank, box);

@@ -562,7 +562,23 @@ struct CollideArgs {
     const uint32_t *sorts_seen;  // tile_ctl[kCtlSortsSeen]
     uint32_t roster_write;       // this run keeps its table: write rosters down
     unsigned long long *stamps;  // diagnostic builds only (-DGPE_TILE_STAMPS): cycles per phase, thread 0
+    // sharded runs: the tiles along the rank's border pack their own particles for the neighbours as they write them
+    // back (gpe_internal.h, pack_particle); pack.on == 0 otherwise
+    PackArgs pack;
 };
+// Does this tile (T x T cells at tile coordinates tx, ty) reach outside the box inside which no particle can concern a
+// neighbour?  (scalar)
+template <int T>
+__device__ __forceinline__ bool tile_packs(const PackArgs &P, const int tx, const int ty)
+{
+    return tx * T < P.ring_x0 || (tx + 1) * T > P.ring_x1 || ty * T < P.ring_y0 || (ty + 1) * T > P.ring_y1;
+}
+// An interior tile's own particle must not end up where a neighbour would care (it would have crossed a block in one step)
+__device__ __forceinline__ void check_stays_inside(const PackArgs &P, const bool mine, const float2 o)
+{
+    if (mine && (o.x < P.safe_x0 || o.x >= P.safe_x1 || o.y < P.safe_y0 || o.y >= P.safe_y1))
+        atomicOr(P.err, kShardErrNoSlot);
+}
 constexpr int kRosterCap = GPE_QMAX_MAIN_VALUE * 512;   // == TileDirect<32, .., 512>::RAWCAP
 
 #ifdef GPE_TILE_STAMPS
@@ -1686,29 +1702,43 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     GPE_STAMP(5);
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
+    const bool packs = ORD && A.pack.on != 0u && tile_packs<T>(A.pack, tx, ty);   // (scalar)
     if constexpr (kTrim) {
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
+            if (q >= 2 && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar, as where own_id was filled)
             const uint32_t id = own_id[q];
-            if (id == 0xFFFFFFFFu) continue;
-            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            const bool have = id != 0xFFFFFFFFu;
+            const uint32_t s = min((uint32_t)tid + (uint32_t)q * kNatThreads, (uint32_t)L::kSlots - 1u);
             const float2 c = make_float2(S.px[s], S.py[s]);
-            if (A.fuse_verlet && id < n_owned) {
+            const float rr = S.rad[s];
+            float2 o = c;
+            const bool mine = have && A.fuse_verlet && id < n_owned;
+            if (mine) {
                 // K12 on the resolved position: the integrated position becomes the live one, the resolved
                 // position the previous one (particle_integration.wgsl:64,76)
-                float2 o;
-                verlet_one(c.x, c.y, own_prev[q].x, own_prev[q].y, S.rad[s], A.vp, o.x, o.y);
+                verlet_one(c.x, c.y, own_prev[q].x, own_prev[q].y, rr, A.vp, o.x, o.y);
                 A.prev[id] = c;
                 A.pos_out[id] = o;
-            } else {
+            } else if (have) {
                 A.pos_out[id] = c;
+            }
+            if constexpr (ORD) {
+                if (packs) pack_particle(A.pack, mine, id, o, c, rr, S.id[s], A.cell_size);
+                else if (A.pack.on) check_stays_inside(A.pack, mine, o);
             }
         }
     } else
-    for (uint32_t s = tid; s < PS; s += kNatThreads) {
-        const uint32_t hm = S.hm[s];
-        if (hm & (1u << 19)) {                                         // the tile's own particle
+    for (uint32_t s0 = 0; s0 < PS; s0 += kNatThreads) {                // (whole waves: the pack uses ballots)
+        const uint32_t s = s0 + (uint32_t)tid;
+        const bool own = s < PS && (S.hm[min(s, PS - 1u)] & (1u << 19)) != 0;
+        bool mine = false;
+        uint32_t pk_id = 0, pk_key = 0;
+        float2 pk_o = make_float2(0.f, 0.f), pk_c = pk_o;
+        float pk_r = 0.f;
+        if (own) {                                                     // the tile's own particle
             uint32_t id = S.id[s];
+            pk_key = id;
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if constexpr (ORD) {                                       // S.id holds the order key: find the block of
                 const uint32_t raw = s;                                // the looked-up slot, re-read the local index
@@ -1733,9 +1763,14 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 verlet_one(c.x, c.y, q.x, q.y, S.rad[s], A.vp, o.x, o.y);
                 A.prev[id] = c;
                 A.pos_out[id] = o;
+                mine = true; pk_id = id; pk_o = o; pk_c = c; pk_r = S.rad[s];
             } else {
                 A.pos_out[id] = c;
             }
+        }
+        if constexpr (ORD) {
+            if (packs) pack_particle(A.pack, mine, pk_id, pk_o, pk_c, pk_r, pk_key, A.cell_size);
+            else if (A.pack.on) check_stays_inside(A.pack, mine, pk_o);
         }
     }
     __syncthreads();
@@ -2485,7 +2520,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
             g_bound = std::min<uint64_t>(c->cap, gh + std::max<uint64_t>(16384, gh / 4));
         }
         g_bound = std::min<uint64_t>(g_bound, n);
-        hg.owned = SH.counts + kShardOwned;
+        hg.owned = SH.counts_now() + kShardOwned;
         hg.gkeys = N.gkeys; hg.gids = N.gids; hg.g_bound = g_bound;
         hg.gtable2 = (uint4 *)N.gtable; hg.gtable_pairs = pairs;
         hg.ghist_now = N.ghist + (size_t)N.ghist_set * kHistSet;       // (two sets, alternating over the steps that use them:
@@ -2496,7 +2531,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         Scope s(c, "native/hash");
         // at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
         const int grid = (int)std::min<uint64_t>(kHashGridMax, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
-        const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr;
+        const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts_now() + kShardTotal : nullptr;
         const uint64_t div_magic = ((1ull << 40) + (uint64_t)N.blocks_x - 1) / (uint64_t)N.blocks_x;
         const auto hash_kernel = kept_sharded ? k_native_hash<true> : k_native_hash<false>;
         hipLaunchKernelGGL(hash_kernel, dim3(grid), dim3(kHashBlock), 0, c->stream, c->pos, c->radius, n, n_valid,
@@ -2713,7 +2748,7 @@ gpe_status native_configure(gpe_ctx *c)
     GPE_TRY(onesweep_reserve(c, c->cap));
     GPE_HIP(c, hipMemsetAsync(N.tile_ctl, 0, kCtlSorts * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_native_check_box, dim3(stream_grid(c->n)), dim3(kStreamBlock), 0, c->stream, c->pos, c->n,
-                       (c->shard.on && c->shard.active) ? c->shard.counts + kShardTotal : nullptr, c->cell_size, N.gx, N.gy,
+                       (c->shard.on && c->shard.active) ? c->shard.counts_now() + kShardTotal : nullptr, c->cell_size, N.gx, N.gy,
                        N.tile_ctl + kCtlError);
     GPE_HIP(c, hipGetLastError());
     uint32_t flag = 1;
@@ -2869,7 +2904,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.blocks_y = N.blocks_y;
     A.bx0 = N.bx0;
     A.by0 = N.by0;
-    A.counts = (c->shard.on && c->shard.active) ? c->shard.counts + kShardOwned : nullptr;
+    A.counts = (c->shard.on && c->shard.active) ? c->shard.counts_now() + kShardOwned : nullptr;
     A.cell_size = c->cell_size;
     A.stiffness = c->cfg.stiffness;
     A.gx = N.gx;
@@ -2894,6 +2929,8 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.fuse_verlet = verlet ? 1u : 0u;
     if (verlet) A.vp = *verlet; else memset(&A.vp, 0, sizeof(A.vp));
     A.stamps = nullptr;
+    A.pack = PackArgs();
+    if (c->shard.on && c->shard.active && c->shard.have_rect && verlet && A.order_keys) shard_pack_args(c, &A.pack);
 #ifdef GPE_TILE_STAMPS
     static unsigned long long *g_stamps = nullptr;
     if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 64 * 8); (void)hipMemset(g_stamps, 0, 64 * 8); }

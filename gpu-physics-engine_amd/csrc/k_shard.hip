@@ -17,6 +17,7 @@
 //
 // The order of the particles inside a rank is free (members of a cell are ordered by their ORDER KEY = index in
 // the unsharded system), so compaction may move any survivor into any hole.
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -25,14 +26,6 @@
 #include "gpe_internal.h"
 
 namespace gpe {
-
-constexpr uint32_t kShardErrSendOverflow = 1u;   // more rows for a neighbour than its segment takes
-constexpr uint32_t kShardErrNoSlot = 2u;         // a particle needs a rank that is not a neighbour (moved > 1 block)
-constexpr uint32_t kShardErrCapacity = 4u;       // owned + ghosts exceed the particle capacity
-constexpr uint32_t kShardErrHoles = 8u;          // more migrants in one step than the hole list takes
-constexpr uint32_t kShardErrRecvOverflow = 16u;  // a received header claims more rows than the segment holds
-constexpr int kSegHeader = 4;                    // words
-constexpr int kMigWords = 6, kGhoWords = 4;
 
 struct ShardArrays {
     float2 *pos, *prev;
@@ -44,119 +37,138 @@ __global__ void k_shard_zero(uint32_t *__restrict__ send, ShardSlots S, uint32_t
 {
     const uint32_t t = threadIdx.x;
     if (t < S.n_slots * kSegHeader) send[S.send_off[t / kSegHeader] + (t % kSegHeader)] = 0;
-    if (t == 0) counts[kShardHoles] = 0;
+    if (t == 0) counts[kShardHoles] = 0;                               // (the set in use)
 }
 
-// rows of one (slot, kind): a wave-aggregated append
-__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
+__global__ __launch_bounds__(kStreamBlock) void k_shard_pack(ShardArrays A, uint64_t n_bound, float cell_size, PackArgs P)
 {
-    const uint64_t m = __ballot(want);
-    if (m == 0) return 0xFFFFFFFFu;
-    const int leader = (int)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    return want ? base + popc_below_lane(m) : 0xFFFFFFFFu;
-}
-
-__global__ __launch_bounds__(kStreamBlock) void k_shard_pack(ShardArrays A, uint64_t n_bound, float cell_size,
-                                                             const uint8_t *__restrict__ owner_of_block,
-                                                             const uint32_t *__restrict__ dest_mask_of_block,
-                                                             int32_t blocks_x, int32_t blocks_y, uint32_t my_rank,
-                                                             ShardSlots S, uint32_t *__restrict__ send,
-                                                             uint32_t *__restrict__ counts,
-                                                             uint32_t *__restrict__ holes,
-                                                             uint8_t *__restrict__ hole_flag, uint32_t holes_cap)
-{
-    const uint64_t n_owned = counts[kShardOwned];
+    const uint64_t n_owned = P.counts[kShardOwned];
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t lim = n_owned < n_bound ? n_owned : n_bound;
     const uint64_t rounds = (lim + stride - 1) / stride;
-    uint32_t err = 0;
     for (uint64_t r = 0; r < rounds; ++r) {
         const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        uint32_t gho = 0;
-        int mig = -1;
-        float2 p = make_float2(0.f, 0.f);
-        if (i < lim) {
-            p = A.pos[i];
-            int bx = cell_coord(p.x, cell_size) >> 3, by = cell_coord(p.y, cell_size) >> 3;
-            bx = min(max(bx, 0), blocks_x - 1);
-            by = min(max(by, 0), blocks_y - 1);
-            const uint32_t b = (uint32_t)by * (uint32_t)blocks_x + (uint32_t)bx;
-            const uint32_t owner = owner_of_block[b];
-            gho = dest_mask_of_block[b] & 0x03FFFFFFu;      // ranks within one block of b, its owner excluded
-            if (owner != my_rank) mig = (int)owner;         // b's owner takes the particle over
-        }
-        if (__ballot(gho != 0 || mig >= 0) == 0) continue;   // interior wave
-        float2 q = make_float2(0.f, 0.f);
-        float rad = 0.f;
-        uint32_t key = 0;
-        if (gho != 0 || mig >= 0) { rad = A.radius[i]; key = A.gid[i]; }
-        if (mig >= 0) q = A.prev[i];
-        {
-            const uint32_t h = wave_append(&counts[kShardHoles], mig >= 0);
-            if (mig >= 0) {
-                if (h < holes_cap) { holes[h] = (uint32_t)i; hole_flag[i] = 1; } else err |= kShardErrHoles;
-                if (S.slot_of_rank[mig & 31] < 0) err |= kShardErrNoSlot;
-            }
-        }
-        uint32_t served = 0;
-        for (uint32_t s = 0; s < S.n_slots; ++s) {
-            const uint32_t rk = S.rank[s];
-            uint32_t *seg = send + S.send_off[s];
-            const bool wm = mig == (int)rk;
-            const bool wg = ((gho >> rk) & 1u) != 0;
-            served |= wg ? (1u << rk) : 0u;
-            const uint32_t rm = wave_append(seg + 0, wm);
-            if (wm) {
-                if (rm < S.send_cap_mig[s]) {
-                    uint32_t *row = seg + kSegHeader + (uint64_t)rm * kMigWords;
-                    row[0] = __float_as_uint(p.x); row[1] = __float_as_uint(p.y);
-                    row[2] = __float_as_uint(q.x); row[3] = __float_as_uint(q.y);
-                    row[4] = __float_as_uint(rad); row[5] = key;
-                } else err |= kShardErrSendOverflow;
-            }
-            const uint32_t rg = wave_append(seg + 1, wg);
-            if (wg) {
-                if (rg < S.send_cap_gho[s]) {
-                    uint32_t *row = seg + kSegHeader + (uint64_t)S.send_cap_mig[s] * kMigWords + (uint64_t)rg * kGhoWords;
-                    row[0] = __float_as_uint(p.x); row[1] = __float_as_uint(p.y);
-                    row[2] = __float_as_uint(rad); row[3] = key;
-                } else err |= kShardErrSendOverflow;
-            }
-        }
-        if (gho & ~served) err |= kShardErrNoSlot;
+        const bool mine = i < lim;
+        const uint64_t ic = mine ? i : 0;
+        // (the rows need radius, key and -- for migrants -- the previous position: loaded for every lane, three cached
+        // streams beside the positions; the first pack of a run only, the steps pack in their tiles)
+        pack_particle(P, mine, (uint32_t)ic, A.pos[ic], A.prev[ic], A.radius[ic], A.gid[ic], cell_size);
     }
-    if (err) atomicOr(&counts[kShardError], err);
 }
 
-// plan[] words: [0] first slot of the arriving migrants of slot s ... ; see k_shard_unpack_plan
-constexpr int kPlanMigOff = 0, kPlanGhoOff = 16, kPlanMigCnt = 32, kPlanGhoCnt = 48;
+// ONE launch consumes what arrived.  Every workgroup derives the same plan from what no workgroup writes during the
+// launch -- the counts of the set in use, the received headers, the capacities: the owned range shrinks by the holes and
+// grows by the arriving migrants, the ghosts follow -- and copies its share of the rows whose destination lies BEYOND the
+// old owned range.  Workgroup 0 alone touches the old range: it compacts it (holes below the new end take the survivors
+// from behind it), then writes the few rows that land in the part of the old range the compaction has vacated, resets
+// the send headers for the next pack, and writes the new counts into the OTHER set, which the kernels behind this one
+// are pointed at (ShardState::parity).  (Rounds 1-3: a one-workgroup plan kernel, then a rows kernel.)
+struct UnpackPlan {
+    uint32_t mig_off[kShardMaxSlots], mig_cnt[kShardMaxSlots], gho_off[kShardMaxSlots], gho_cnt[kShardMaxSlots];
+    uint32_t n0, base, n_owned, total, err;
+};
 
-// One workgroup: compaction of the owned range (holes below the new end take survivors from behind it), then the
-// destination offsets of everything that arrived, then the new counts.
-__global__ __launch_bounds__(1024) void k_shard_unpack_plan(ShardArrays A, ShardSlots S,
-                                                            const uint32_t *__restrict__ send,
-                                                            const uint32_t *__restrict__ recv,
-                                                            uint32_t *__restrict__ counts,
-                                                            uint32_t *__restrict__ host_counts,
-                                                            uint32_t *__restrict__ plan,
-                                                            uint32_t *__restrict__ holes,
-                                                            uint8_t *__restrict__ hole_flag,
-                                                            uint32_t *__restrict__ fill_src,
-                                                            uint32_t *__restrict__ fill_dst, uint32_t holes_cap,
-                                                            uint64_t capacity)
+__device__ __forceinline__ void unpack_rows_of(const ShardArrays &A, const ShardSlots &S, const uint32_t *send,
+                                               const uint32_t *recv, const UnpackPlan &U, uint32_t t0, uint32_t stride,
+                                               uint32_t lo, uint32_t hi)
 {
+    // rows whose destination d satisfies lo <= d < hi
+    for (uint32_t s = 0; s < S.n_slots; ++s) {
+        const bool self = s + 1 == S.n_slots;
+        const uint32_t *seg = self ? send + S.send_off[s] : recv + S.recv_off[s];
+        const uint32_t cap_mig = self ? S.send_cap_mig[s] : S.recv_cap_mig[s];
+        if (!self) {
+            const uint32_t cnt = U.mig_cnt[s], off = U.mig_off[s];
+            const uint32_t j0 = lo > off ? lo - off : 0u, j1 = hi > off ? min(cnt, hi - off) : 0u;
+            for (uint32_t j = j0 + t0; j < j1; j += stride) {
+                const uint32_t *row = seg + kSegHeader + (uint64_t)j * kMigWords;
+                A.pos[off + j] = make_float2(__uint_as_float(row[0]), __uint_as_float(row[1]));
+                A.prev[off + j] = make_float2(__uint_as_float(row[2]), __uint_as_float(row[3]));
+                A.radius[off + j] = __uint_as_float(row[4]);
+                A.gid[off + j] = row[5];
+            }
+        }
+        const uint32_t cnt = U.gho_cnt[s], off = U.gho_off[s];
+        const uint32_t j0 = lo > off ? lo - off : 0u, j1 = hi > off ? min(cnt, hi - off) : 0u;
+        for (uint32_t j = j0 + t0; j < j1; j += stride) {
+            const uint32_t *row = seg + kSegHeader + (uint64_t)cap_mig * kMigWords + (uint64_t)j * kGhoWords;
+            A.pos[off + j] = make_float2(__uint_as_float(row[0]), __uint_as_float(row[1]));
+            A.radius[off + j] = __uint_as_float(row[2]);
+            A.gid[off + j] = row[3];
+        }
+    }
+}
+
+constexpr int kUnpackBlock = 1024, kUnpackGrid = 32;
+__global__ __launch_bounds__(kUnpackBlock) void k_shard_unpack(ShardArrays A, ShardSlots S, uint32_t *send,
+                                                               const uint32_t *__restrict__ recv,
+                                                               const uint32_t *__restrict__ counts_old,
+                                                               uint32_t *__restrict__ counts_new,
+                                                               uint32_t *__restrict__ err_word,
+                                                               uint32_t *__restrict__ done_ticket,
+                                                               uint32_t *__restrict__ host_counts,
+                                                               uint32_t *__restrict__ holes,
+                                                               uint8_t *__restrict__ hole_flag,
+                                                               uint32_t *__restrict__ fill_src,
+                                                               uint32_t *__restrict__ fill_dst, uint32_t holes_cap,
+                                                               uint64_t capacity)
+{
+    __shared__ UnpackPlan U;
     __shared__ uint32_t s_ns, s_nh;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { s_ns = 0; s_nh = 0; }
+    if (tid == 0) {
+        s_ns = 0; s_nh = 0;
+        const uint32_t n0 = counts_old[kShardOwned];
+        uint32_t m = counts_old[kShardHoles];
+        if (m > holes_cap) m = holes_cap;
+        if (m > n0) m = n0;
+        uint32_t err = 0;
+        uint64_t o = n0 - m;
+        U.n0 = n0; U.base = n0 - m;
+        for (uint32_t s = 0; s + 1 < S.n_slots; ++s) {                 // neighbours; the last slot is this rank
+            uint32_t c = recv[S.recv_off[s] + 0];
+            if (c > S.recv_cap_mig[s]) { c = S.recv_cap_mig[s]; err |= kShardErrRecvOverflow; }
+            if (o + c > capacity) { c = 0; err |= kShardErrCapacity; }
+            U.mig_off[s] = (uint32_t)o;
+            U.mig_cnt[s] = c;
+            o += c;
+        }
+        U.n_owned = (uint32_t)o;
+        for (uint32_t s = 0; s < S.n_slots; ++s) {
+            const bool self = s + 1 == S.n_slots;
+            uint32_t c = self ? send[S.send_off[s] + 1] : recv[S.recv_off[s] + 1];
+            const uint32_t cap = self ? S.send_cap_gho[s] : S.recv_cap_gho[s];
+            if (c > cap) { c = cap; err |= self ? kShardErrSendOverflow : kShardErrRecvOverflow; }
+            if (o + c > capacity) { c = 0; err |= kShardErrCapacity; }
+            U.gho_off[s] = (uint32_t)o;
+            U.gho_cnt[s] = c;
+            o += c;
+        }
+        U.total = (uint32_t)o;
+        U.err = err;
+    }
     __syncthreads();
-    const uint32_t n0 = counts[kShardOwned];
-    uint32_t m = counts[kShardHoles];
-    if (m > holes_cap) m = holes_cap;
-    if (m > n0) m = n0;
-    const uint32_t base = n0 - m;
+    const uint32_t n0 = U.n0, base = U.base;
+    // rows that land beyond the old owned range: everybody's job
+    unpack_rows_of(A, S, send, recv, U, blockIdx.x * blockDim.x + tid, gridDim.x * blockDim.x, n0, 0xFFFFFFFFu);
+    if (blockIdx.x != 0) {
+        // The segment headers have been consumed -- by the plan of EVERY workgroup: the last one to get here resets them
+        // for the next pack (the tiles of the coming step append to them), which then needs no launch of its own for that.
+        __syncthreads();
+        __shared__ uint32_t s_last;
+        if (tid == 0) {
+            __threadfence();
+            s_last = atomicAdd(done_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_last) {
+            if (tid < S.n_slots * kSegHeader) send[S.send_off[tid / kSegHeader] + (tid % kSegHeader)] = 0;
+            if (tid == 0) *done_ticket = 0u;
+        }
+        return;
+    }
+    // ---- workgroup 0: compaction of the old range, then the rows that land in it ----
+    const uint32_t m = n0 - base;
     for (uint32_t t = tid; t < m; t += blockDim.x) {
         const uint32_t slot = base + t;
         if (!hole_flag[slot]) fill_src[atomicAdd(&s_ns, 1u)] = slot;
@@ -170,74 +182,34 @@ __global__ __launch_bounds__(1024) void k_shard_unpack_plan(ShardArrays A, Shard
         A.pos[b] = A.pos[a]; A.prev[b] = A.prev[a]; A.radius[b] = A.radius[a]; A.gid[b] = A.gid[a];
     }
     for (uint32_t t = tid; t < m; t += blockDim.x) hole_flag[holes[t]] = 0;
+    __syncthreads();                                                   // (the moves have read the tail: it may be overwritten now)
+    unpack_rows_of(A, S, send, recv, U, tid, blockDim.x, base, n0);
     __syncthreads();
-    if (tid == 0) {
-        uint32_t err = (s_ns != s_nh) ? kShardErrHoles : 0u;
-        uint64_t o = base;
-        for (uint32_t s = 0; s + 1 < S.n_slots; ++s) {                 // neighbours; the last slot is this rank
-            uint32_t c = recv[S.recv_off[s] + 0];
-            if (c > S.recv_cap_mig[s]) { c = S.recv_cap_mig[s]; err |= kShardErrRecvOverflow; }
-            if (o + c > capacity) { c = 0; err |= kShardErrCapacity; }
-            plan[kPlanMigOff + s] = (uint32_t)o;
-            plan[kPlanMigCnt + s] = c;
-            o += c;
+    {
+        __shared__ uint32_t s_last0;
+        if (tid == 0) {
+            __threadfence();
+            s_last0 = atomicAdd(done_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
         }
-        const uint32_t n_owned = (uint32_t)o;
-        for (uint32_t s = 0; s < S.n_slots; ++s) {
-            const bool self = s + 1 == S.n_slots;
-            uint32_t c = self ? send[S.send_off[s] + 1] : recv[S.recv_off[s] + 1];
-            const uint32_t cap = self ? S.send_cap_gho[s] : S.recv_cap_gho[s];
-            if (c > cap) { c = cap; err |= self ? kShardErrSendOverflow : kShardErrRecvOverflow; }
-            if (o + c > capacity) { c = 0; err |= kShardErrCapacity; }
-            plan[kPlanGhoOff + s] = (uint32_t)o;
-            plan[kPlanGhoCnt + s] = c;
-            o += c;
+        __syncthreads();
+        if (s_last0) {                                                 // (see above: the last workgroup resets the headers)
+            if (tid < S.n_slots * kSegHeader) send[S.send_off[tid / kSegHeader] + (tid % kSegHeader)] = 0;
+            if (tid == 0) *done_ticket = 0u;
         }
-        const uint32_t epoch = counts[kShardEpoch] + 1u;
-        counts[kShardOwned] = n_owned;
-        counts[kShardTotal] = (uint32_t)o;
-        counts[kShardEpoch] = epoch;
-        counts[kShardHoles] = 0;
-        if (err) atomicOr(&counts[kShardError], err);
-        // pinned mirror: the epoch last, so a host that sees it also sees the counts of that epoch or newer
-        __hip_atomic_store(&host_counts[kShardOwned], n_owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_counts[kShardTotal], (uint32_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_counts[kShardError], counts[kShardError] | err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_counts[kShardEpoch], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-}
-
-__global__ __launch_bounds__(kStreamBlock) void k_shard_unpack_rows(ShardArrays A, ShardSlots S, uint32_t *send,
-                                                                    const uint32_t *__restrict__ recv,
-                                                                    const uint32_t *__restrict__ plan)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
-    // the segment headers have been consumed by k_shard_unpack_plan (the rows below start behind them): reset them
-    // for the next pack, which then needs no launch of its own for that
-    if (blockIdx.x == 0 && threadIdx.x < S.n_slots * kSegHeader)
-        send[S.send_off[threadIdx.x / kSegHeader] + (threadIdx.x % kSegHeader)] = 0;
-    for (uint32_t s = 0; s < S.n_slots; ++s) {
-        const bool self = s + 1 == S.n_slots;
-        const uint32_t *seg = self ? send + S.send_off[s] : recv + S.recv_off[s];
-        const uint32_t cap_mig = self ? S.send_cap_mig[s] : S.recv_cap_mig[s];
-        if (!self) {
-            const uint32_t cnt = plan[kPlanMigCnt + s], off = plan[kPlanMigOff + s];
-            for (uint32_t j = t0; j < cnt; j += stride) {
-                const uint32_t *row = seg + kSegHeader + (uint64_t)j * kMigWords;
-                A.pos[off + j] = make_float2(__uint_as_float(row[0]), __uint_as_float(row[1]));
-                A.prev[off + j] = make_float2(__uint_as_float(row[2]), __uint_as_float(row[3]));
-                A.radius[off + j] = __uint_as_float(row[4]);
-                A.gid[off + j] = row[5];
-            }
-        }
-        const uint32_t cnt = plan[kPlanGhoCnt + s], off = plan[kPlanGhoOff + s];
-        for (uint32_t j = t0; j < cnt; j += stride) {
-            const uint32_t *row = seg + kSegHeader + (uint64_t)cap_mig * kMigWords + (uint64_t)j * kGhoWords;
-            A.pos[off + j] = make_float2(__uint_as_float(row[0]), __uint_as_float(row[1]));
-            A.radius[off + j] = __uint_as_float(row[2]);
-            A.gid[off + j] = row[3];
-        }
+    if (tid == 0) {
+        const uint32_t err = U.err | ((s_ns != s_nh) ? kShardErrHoles : 0u);
+        const uint32_t epoch = counts_old[kShardEpoch] + 1u;
+        counts_new[kShardOwned] = U.n_owned;
+        counts_new[kShardTotal] = U.total;
+        counts_new[kShardEpoch] = epoch;
+        counts_new[kShardHoles] = 0;
+        if (err) atomicOr(err_word, err);
+        // pinned mirror: the epoch last, so a host that sees it also sees the counts of that epoch or newer
+        __hip_atomic_store(&host_counts[kShardOwned], U.n_owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_counts[kShardTotal], U.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_counts[kShardError], *err_word | err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_counts[kShardEpoch], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -259,7 +231,6 @@ void shard_release(gpe_ctx *c)
 {
     ShardState &S = c->shard;
     if (S.counts) (void)hipFree(S.counts);
-    if (S.plan) (void)hipFree(S.plan);
     if (S.holes) (void)hipFree(S.holes);
     if (S.fill_src) (void)hipFree(S.fill_src);
     if (S.fill_dst) (void)hipFree(S.fill_dst);
@@ -300,18 +271,49 @@ static gpe_status ensure_flag_capacity(gpe_ctx *c)
 
 gpe_status shard_ensure_flag_capacity(gpe_ctx *c) { return ensure_flag_capacity(c); }
 
+// what a pack needs (PackArgs): the plan's tables, the segments, the hole list; `on` and the ring / safe boxes are for the
+// tiles of the native step and only set when the plan told the rank's rectangle
+void shard_pack_args(gpe_ctx *c, PackArgs *P)
+{
+    const ShardState &S = c->shard;
+    *P = PackArgs();
+    P->owner = S.owner; P->dest_mask = S.dest_mask; P->blocks_x = S.blocks_x; P->blocks_y = S.blocks_y;
+    P->my_rank = S.my_rank;
+    P->send = S.send; P->counts = S.counts_now(); P->err = S.counts + kShardError; P->holes = S.holes; P->hole_flag = S.hole_flag;
+    P->holes_cap = (uint32_t)S.holes_cap;
+    P->slots = S.slots;
+    if (S.have_rect && S.active) {
+        // Who can need packing: a particle whose NEW block is owned by another rank or borders one, i.e. lies in the
+        // outermost block ring of the rectangle or beyond.  It moved less than a block this step (the exchange's
+        // premise), so its home cell at the start of the step lay within two blocks of the rectangle's edge.
+        const int x0 = S.rect[0], y0 = S.rect[1], x1 = S.rect[2], y1 = S.rect[3];
+        const bool nb_l = x0 > 0, nb_r = x1 < S.blocks_x, nb_d = y0 > 0, nb_u = y1 < S.blocks_y;
+        P->ring_x0 = nb_l ? (x0 + 2) * 8 : -(1 << 30);
+        P->ring_y0 = nb_d ? (y0 + 2) * 8 : -(1 << 30);
+        P->ring_x1 = nb_r ? (x1 - 2) * 8 : (1 << 30);
+        P->ring_y1 = nb_u ? (y1 - 2) * 8 : (1 << 30);
+        const float cs = c->cell_size, big = 3.0e38f;
+        P->safe_x0 = nb_l ? (float)((x0 + 1) * 8 + 1) * cs : -big;
+        P->safe_y0 = nb_d ? (float)((y0 + 1) * 8 + 1) * cs : -big;
+        P->safe_x1 = nb_r ? (float)((x1 - 1) * 8 - 1) * cs : big;
+        P->safe_y1 = nb_u ? (float)((y1 - 1) * 8 - 1) * cs : big;
+        P->on = 1u;
+    }
+}
+
 static gpe_status launch_pack(gpe_ctx *c, bool reset_headers)
 {
     ShardState &S = c->shard;
     Scope s(c, "shard/pack");
     if (reset_headers) {                                               // the first pack of a run; later ones find
-        hipLaunchKernelGGL(k_shard_zero, dim3(1), dim3(64), 0, c->stream, S.send, S.slots, S.counts);   // them reset by the unpack
+        hipLaunchKernelGGL(k_shard_zero, dim3(1), dim3(64), 0, c->stream, S.send, S.slots, S.counts_now());   // them reset by the unpack
         GPE_HIP(c, hipGetLastError());
     }
     const uint64_t bound = std::min<uint64_t>(c->cap, c->n);          // owned <= total <= bound
+    PackArgs P;
+    shard_pack_args(c, &P);
     hipLaunchKernelGGL(k_shard_pack, dim3(stream_grid(bound)), dim3(kStreamBlock), 0, c->stream, shard_arrays(c), bound,
-                       c->cell_size, S.owner, S.dest_mask, S.blocks_x, S.blocks_y, S.my_rank, S.slots, S.send, S.counts,
-                       S.holes, S.hole_flag, (uint32_t)S.holes_cap);
+                       c->cell_size, P);
     GPE_HIP(c, hipGetLastError());
     S.packed = true;
     return GPE_OK;
@@ -321,12 +323,11 @@ static gpe_status launch_unpack(gpe_ctx *c)
 {
     ShardState &S = c->shard;
     Scope s(c, "shard/unpack");
-    hipLaunchKernelGGL(k_shard_unpack_plan, dim3(1), dim3(1024), 0, c->stream, shard_arrays(c), S.slots, S.send, S.recv,
-                       S.counts, S.host_counts, S.plan, S.holes, S.hole_flag, S.fill_src, S.fill_dst,
-                       (uint32_t)S.holes_cap, c->cap);
-    GPE_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_shard_unpack_rows, dim3(128), dim3(kStreamBlock), 0, c->stream, shard_arrays(c), S.slots, S.send,
-                       S.recv, S.plan);
+    uint32_t *old_set = S.counts_now();
+    S.parity ^= 1u;                                                    // the kernels behind this launch read the new set
+    hipLaunchKernelGGL(k_shard_unpack, dim3(kUnpackGrid), dim3(kUnpackBlock), 0, c->stream, shard_arrays(c), S.slots, S.send,
+                       S.recv, old_set, S.counts_now(), S.counts + kShardError, S.counts + kShardDoneTicket, S.host_counts, S.holes, S.hole_flag,
+                       S.fill_src, S.fill_dst, (uint32_t)S.holes_cap, c->cap);
     GPE_HIP(c, hipGetLastError());
     S.packed = false;
     return GPE_OK;
@@ -354,7 +355,8 @@ static gpe_status shard_grow_if_needed(gpe_ctx *c)
     if ((int32_t)(epoch - S.begin_epoch) <= 0) return GPE_OK;
     if ((uint64_t)S.host_counts[kShardTotal] * 4 < c->cap * 3) return GPE_OK;
     uint32_t w[5] = {0, 0, 0, 0, 0};
-    GPE_HIP(c, hipMemcpyAsync(w, S.counts, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipMemcpyAsync(w, S.counts_now(), sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipMemcpyAsync(&w[kShardError], S.counts + kShardError, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     if (w[kShardError]) return fail(c, GPE_ERR_UNSUPPORTED, shard_error_text(w[kShardError]));
     const uint64_t total = w[kShardTotal];
@@ -376,7 +378,9 @@ extern "C" {
 gpe_status gpe_shard_configure(gpe_ctx *c, const gpe_shard_plan *p)
 {
     if (!c) return GPE_ERR_INVALID_ARG;
-    if (!p || p->struct_size != sizeof(gpe_shard_plan)) return fail(c, GPE_ERR_INVALID_ARG, "gpe_shard_configure: bad plan");
+    constexpr uint32_t kPlanV1 = (uint32_t)offsetof(gpe_shard_plan, own_x0);     // the plan before it told the rectangle
+    if (!p || (p->struct_size != sizeof(gpe_shard_plan) && p->struct_size != kPlanV1))
+        return fail(c, GPE_ERR_INVALID_ARG, "gpe_shard_configure: bad plan");
     if (c->n == 0 || !c->pos) return fail(c, GPE_ERR_STATE, "no particles: call gpe_set_particles first");
     if (p->n_slots < 1 || p->n_slots > (uint32_t)kShardMaxSlots || p->world_size > 26 || p->rank >= p->world_size ||
         !p->d_owner_of_block || !p->d_dest_mask_of_block || !p->d_send || !p->d_recv || p->blocks_x <= 0 || p->blocks_y <= 0 ||
@@ -389,6 +393,13 @@ gpe_status gpe_shard_configure(gpe_ctx *c, const gpe_shard_plan *p)
     S.blocks_x = p->blocks_x; S.blocks_y = p->blocks_y;
     S.owner = p->d_owner_of_block; S.dest_mask = p->d_dest_mask_of_block;
     S.send = p->d_send; S.recv = p->d_recv;
+    S.have_rect = false;
+    if (p->struct_size == sizeof(gpe_shard_plan) && p->own_x1 > p->own_x0 && p->own_y1 > p->own_y0) {
+        if (p->own_x0 < 0 || p->own_y0 < 0 || p->own_x1 > p->blocks_x || p->own_y1 > p->blocks_y)
+            return fail(c, GPE_ERR_INVALID_ARG, "gpe_shard_configure: the rank's rectangle lies outside the block grid");
+        S.rect[0] = p->own_x0; S.rect[1] = p->own_y0; S.rect[2] = p->own_x1; S.rect[3] = p->own_y1;
+        S.have_rect = true;
+    }
     memset(&S.slots, 0, sizeof(S.slots));
     S.slots.n_slots = p->n_slots;
     for (int r = 0; r < 32; ++r) S.slots.slot_of_rank[r] = -1;
@@ -400,9 +411,8 @@ gpe_status gpe_shard_configure(gpe_ctx *c, const gpe_shard_plan *p)
         S.slots.recv_off[s] = p->recv_off[s]; S.slots.recv_cap_mig[s] = p->recv_cap_mig[s]; S.slots.recv_cap_gho[s] = p->recv_cap_gho[s];
     }
     if (!S.counts) {
-        GPE_HIP(c, hipMalloc((void **)&S.counts, 64));
-        GPE_HIP(c, hipMemset(S.counts, 0, 64));
-        GPE_HIP(c, hipMalloc((void **)&S.plan, 64 * sizeof(uint32_t)));
+        GPE_HIP(c, hipMalloc((void **)&S.counts, 2 * kShardSetWords * sizeof(uint32_t)));
+        GPE_HIP(c, hipMemset(S.counts, 0, 2 * kShardSetWords * sizeof(uint32_t)));
         GPE_HIP(c, hipHostMalloc((void **)&S.host_counts, 64, hipHostMallocDefault));
         memset(S.host_counts, 0, 64);
     }
@@ -437,7 +447,9 @@ gpe_status gpe_shard_begin(gpe_ctx *c)
     c->n = c->n_owned;
     GPE_HIP(c, hipStreamSynchronize(c->stream));                       // every earlier unpack has landed
     const uint32_t epoch = S.host_counts[kShardEpoch] + 1u;            // the mirror counts from here
+    // (the sticky error word is word kShardError of set 0 whichever set is in use: a new run starts without one)
     const uint32_t init[5] = {(uint32_t)c->n_owned, (uint32_t)c->n_owned, 0u, epoch, 0u};
+    S.parity = 0;
     GPE_HIP(c, hipMemcpyAsync(S.counts, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     S.begin_epoch = epoch;
@@ -476,7 +488,12 @@ gpe_status gpe_shard_step(gpe_ctx *c, float dt)
     c->n = shard_bound(c);
     if (st == GPE_OK) st = step_for_shard(c, dt);
     c->profiling = on;
-    if (st == GPE_OK) st = launch_pack(c, false);
+    // the tiles of the step packed their own particles as they wrote them back (native_collide, PackArgs.on); a plan
+    // that does not tell the rank's rectangle leaves it to the pack kernel
+    if (st == GPE_OK) {
+        if (S.have_rect) S.packed = true;
+        else st = launch_pack(c, false);
+    }
     if (sampled) c->profiling = true;
     return st;
 }
@@ -498,7 +515,8 @@ gpe_status gpe_shard_counts(gpe_ctx *c, uint64_t *n_owned, uint64_t *n_total, in
     GPE_TRY(shard_ready(c, true));
     ShardState &S = c->shard;
     uint32_t w[5] = {0, 0, 0, 0, 0};
-    GPE_HIP(c, hipMemcpyAsync(w, S.counts, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipMemcpyAsync(w, S.counts_now(), sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    GPE_HIP(c, hipMemcpyAsync(&w[kShardError], S.counts + kShardError, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));
     if (n_owned) *n_owned = w[kShardOwned];
     if (n_total) *n_total = w[kShardTotal];

@@ -270,6 +270,9 @@ typedef struct gpe_shard_plan {
     uint32_t send_off[9], send_cap_mig[9], send_cap_gho[9];   /* word offsets into d_send, rows   */
     uint32_t recv_off[9], recv_cap_mig[9], recv_cap_gho[9];   /* word offsets into d_recv, rows   */
     uint32_t *d_send, *d_recv;
+    int32_t  own_x0, own_y0, own_x1, own_y1;   /* the rank's rectangle in blocks, half-open (all 0: not told).  Told, the  */
+                                               /* tiles of the step pack their own particles as they write them back and   */
+                                               /* no pack kernel runs (struct_size without these four is accepted too)     */
 } gpe_shard_plan;
 gpe_status gpe_shard_configure(gpe_ctx *ctx, const gpe_shard_plan *plan);
 /* Counts go to the device (owned = total = the host's owned count, ghosts dropped); packs the first segments. */

@@ -39,6 +39,7 @@ plan.recv_off[0], plan.recv_cap_mig[0], plan.recv_cap_gho[0] = 0, cap_mig, cap_g
 plan.slot_rank[1], plan.send_off[1], plan.send_cap_mig[1], plan.send_cap_gho[1] = 0, words, 0, cap_mig
 plan.recv_off[1], plan.recv_cap_mig[1], plan.recv_cap_gho[1] = words, 0, 0
 plan.d_send, plan.d_recv = send.value, recv.value
+plan.own_x0, plan.own_y0, plan.own_x1, plan.own_y1 = 0, 0, bx, by     # the rank's rectangle: the tiles pack, no pack kernel
 ctx.call("gpe_shard_configure", C.byref(plan))
 ident = (C.c_uint8 * L.COMM_ID_BYTES)(); assert L.load().gpe_comm_unique_id(ident) == 0
 ctx.call("gpe_shard_comm_init", ident, 0, 1)
