@@ -363,11 +363,8 @@ struct PackArgs {
     uint32_t *err = nullptr;                     // the sticky error word
     uint8_t *hole_flag = nullptr;
     uint32_t holes_cap = 0;
-    // the tiles: only tiles that reach outside this cell box (the rank's rectangle shrunk by two blocks on every side
-    // that has a neighbour) can hold a particle the neighbours care about; the others check that none of theirs ended
-    // up outside the `safe` box (world units: the rectangle shrunk by one block + one cell) -- that would be a particle
-    // that crossed a whole block in one step, which the exchange does not cover (kShardErrNoSlot)
-    int32_t ring_x0 = 0, ring_y0 = 0, ring_x1 = 0, ring_y1 = 0;
+    // the tiles: a new position inside the `safe` box (world units: the rank's rectangle shrunk by one block + one cell on
+    // every side that has a neighbour) concerns no other rank -- its block is this rank's and borders nobody
     float safe_x0 = 0.f, safe_y0 = 0.f, safe_x1 = 0.f, safe_y1 = 0.f;
     uint32_t on = 0;
     ShardSlots slots;

@@ -566,18 +566,16 @@ struct CollideArgs {
     // back (gpe_internal.h, pack_particle); pack.on == 0 otherwise
     PackArgs pack;
 };
-// Does this tile (T x T cells at tile coordinates tx, ty) reach outside the box inside which no particle can concern a
-// neighbour?  (scalar)
-template <int T>
-__device__ __forceinline__ bool tile_packs(const PackArgs &P, const int tx, const int ty)
+// The pack as the tiles do it: a particle whose new position lies inside the `safe` box (the rank's rectangle shrunk by
+// one block and a cell on every side that has a neighbour) sits in a block this rank owns and no other rank borders --
+// four compares say so, no table lookup; only the others go through pack_particle (a wave none of whose lanes holds one
+// skips it: every tile away from the rank's border, whatever the speed of its particles).
+__device__ __forceinline__ void pack_if_near_border(const PackArgs &P, const bool mine, const uint32_t id, const float2 o,
+                                                    const float2 c, const float rad, const uint32_t key, const float cell_size)
 {
-    return tx * T < P.ring_x0 || (tx + 1) * T > P.ring_x1 || ty * T < P.ring_y0 || (ty + 1) * T > P.ring_y1;
-}
-// An interior tile's own particle must not end up where a neighbour would care (it would have crossed a block in one step)
-__device__ __forceinline__ void check_stays_inside(const PackArgs &P, const bool mine, const float2 o)
-{
-    if (mine && (o.x < P.safe_x0 || o.x >= P.safe_x1 || o.y < P.safe_y0 || o.y >= P.safe_y1))
-        atomicOr(P.err, kShardErrNoSlot);
+    const bool near = mine && (o.x < P.safe_x0 || o.x >= P.safe_x1 || o.y < P.safe_y0 || o.y >= P.safe_y1);
+    if (__ballot(near) == 0) return;
+    pack_particle(P, near, id, o, c, rad, key, cell_size);
 }
 constexpr int kRosterCap = GPE_QMAX_MAIN_VALUE * 512;   // == TileDirect<32, .., 512>::RAWCAP
 
@@ -1702,7 +1700,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     GPE_STAMP(5);
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
-    const bool packs = ORD && A.pack.on != 0u && tile_packs<T>(A.pack, tx, ty);   // (scalar)
+    const bool packs = ORD && A.pack.on != 0u;                         // (scalar) a sharded step: the tiles pack
     if constexpr (kTrim) {
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
@@ -1724,8 +1722,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 A.pos_out[id] = c;
             }
             if constexpr (ORD) {
-                if (packs) pack_particle(A.pack, mine, id, o, c, rr, S.id[s], A.cell_size);
-                else if (A.pack.on) check_stays_inside(A.pack, mine, o);
+                if (packs) pack_if_near_border(A.pack, mine, id, o, c, rr, S.id[s], A.cell_size);
             }
         }
     } else
@@ -1769,8 +1766,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             }
         }
         if constexpr (ORD) {
-            if (packs) pack_particle(A.pack, mine, pk_id, pk_o, pk_c, pk_r, pk_key, A.cell_size);
-            else if (A.pack.on) check_stays_inside(A.pack, mine, pk_o);
+            if (packs) pack_if_near_border(A.pack, mine, pk_id, pk_o, pk_c, pk_r, pk_key, A.cell_size);
         }
     }
     __syncthreads();

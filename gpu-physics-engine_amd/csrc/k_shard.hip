@@ -284,14 +284,9 @@ void shard_pack_args(gpe_ctx *c, PackArgs *P)
     P->slots = S.slots;
     if (S.have_rect && S.active) {
         // Who can need packing: a particle whose NEW block is owned by another rank or borders one, i.e. lies in the
-        // outermost block ring of the rectangle or beyond.  It moved less than a block this step (the exchange's
-        // premise), so its home cell at the start of the step lay within two blocks of the rectangle's edge.
+        // outermost block ring of the rectangle or beyond; one cell of margin covers the rounding of the box's edges.
         const int x0 = S.rect[0], y0 = S.rect[1], x1 = S.rect[2], y1 = S.rect[3];
         const bool nb_l = x0 > 0, nb_r = x1 < S.blocks_x, nb_d = y0 > 0, nb_u = y1 < S.blocks_y;
-        P->ring_x0 = nb_l ? (x0 + 2) * 8 : -(1 << 30);
-        P->ring_y0 = nb_d ? (y0 + 2) * 8 : -(1 << 30);
-        P->ring_x1 = nb_r ? (x1 - 2) * 8 : (1 << 30);
-        P->ring_y1 = nb_u ? (y1 - 2) * 8 : (1 << 30);
         const float cs = c->cell_size, big = 3.0e38f;
         P->safe_x0 = nb_l ? (float)((x0 + 1) * 8 + 1) * cs : -big;
         P->safe_y0 = nb_d ? (float)((y0 + 1) * 8 + 1) * cs : -big;
