@@ -252,6 +252,13 @@ struct OnesweepWorkspace {
     uint32_t hist_set = 0;           // which of the two sets of copies that is
 };
 
+// Straggler lists, ghost lists and rosters are indexed by the tile's position in the TILE BOX of the run: the whole cell
+// box, or a sharded rank's active box (so that their memory follows the rank's share of the world, not the world).
+struct TileBox {
+    int32_t x0 = 0, y0 = 0, nx = 0, ny = 0;     // first tile (32x32 cells), tiles per row / column
+    __host__ __device__ __forceinline__ bool holds(int tx, int ty) const { return tx >= x0 && ty >= y0 && tx < x0 + nx && ty < y0 + ny; }
+    __host__ __device__ __forceinline__ uint32_t index(int tx, int ty) const { return (uint32_t)(ty - y0) * (uint32_t)nx + (uint32_t)(tx - x0); }
+};
 constexpr int kNativeCtlSorts = 14;         // tile_ctl word: running count of steps whose radix passes ran (k_native.hip kCtlSorts)
 constexpr int kNativeCtlSortsSeen = 38;     // its copy in the line the tiles only read (k_native.hip kCtlSortsSeen)
 // Native (N-key sort + LDS cell windows) pipeline state
@@ -280,7 +287,10 @@ struct NativeState {
     uint4 *roster_hdr = nullptr;           // tile rosters (k_native.hip, CollideArgs)
     uint32_t *roster_ids = nullptr;
     uint64_t roster_cap = 0;
-    int32_t exc_tiles_x = 0, exc_tiles_y = 0;
+    TileBox tb;                      // the tiles the straggler lists, ghost lists and rosters are kept for
+    uint32_t *gho_count = nullptr;   // sharded runs: ghost lists, [2][exc_tiles] counts then [2][exc_tiles][kGhostSlots] ids
+    uint64_t gho_cap = 0;
+    const uint32_t *gho_count_now = nullptr, *gho_entry_now = nullptr, *ghost_sort_now = nullptr;   // what this step's tiles read
     const uint32_t *exc_count_now = nullptr;   // the set the current step's tiles read (NULL: the step sorts anyway)
     const uint2 *exc_entry_now = nullptr;
     uint32_t *sorted_key = nullptr;  // per particle: the block key it had when the radix passes last ran (written by their

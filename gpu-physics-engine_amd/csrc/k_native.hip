@@ -101,6 +101,7 @@ constexpr int kCtlSorts = kNativeCtlSorts;     // steps whose radix passes ran (
 constexpr int kCtlStragglers0 = 9, kCtlStragglers1 = 15;   // [parity] stragglers found by the step's hash so far
 constexpr int kCtlSortedCount = 32;            // particles the kept grouping covers (written by the first radix pass)
 constexpr int kCtlSortsSeen = kNativeCtlSortsSeen;   // copy of kCtlSorts in the line the tiles only read (written by the last radix pass)
+constexpr int kCtlGhostSort = 40;              // [parity] sharded: a tile's ghost list ran over -- the ghosts' radix passes run and the tiles look the ghosts up in their block table
 constexpr int kCtlWords = 64;                  // tile_ctl is this long (two 128-byte lines)
 // How far a particle may have left the 8x8-cell block it was sorted into (cells beyond the block's extent, per
 // direction) and still be found by every tile that needs it.  A tile looks up the blocks of tile +- 8 cells but keeps
@@ -119,6 +120,11 @@ constexpr int kCodeYShift = 7, kCodeOverlapShift = 14;
 // tile's list running over raises kCtlNeedSort.  Two sets of lists, by step parity (reset like the control words).
 constexpr uint32_t kExcSlots = 16;
 constexpr uint32_t kCodeStraggler = 1u << 22;
+// Sharded runs: the ghosts (copies of the neighbours' particles, new every step) reach the tiles the same way -- the hash
+// kernel lists every ghost for the 32x32 tiles whose window holds its cell, kGhostSlots per tile (a tile on the rank's
+// border sees ~60-150 at the benchmark density).  Only when a list runs over do the ghosts get sorted into a block
+// table of their own (rounds 1-3 did that every step: two radix launches).
+constexpr uint32_t kGhostSlots = 256;
 static_assert(kDriftRight <= kHalo - (kConeLeft + 1) && kDriftLeft <= kHalo - (kConeRight + 1), "x drift inside the lookup slack");
 static_assert(kDriftUp <= kHalo - (kConeDown + 1) && kDriftDown <= kHalo - (kConeUp + 1), "y drift inside the lookup slack");
 static_assert(64 + 2 * kHalo + kDriftLeft + kDriftRight < 128 && 32 + 2 * kHalo + kDriftDown + kDriftUp < 128, "a lookup region + drift names every cell mod 128 once");
@@ -216,6 +222,9 @@ struct HashGhosts {
     uint64_t gtable_pairs = 0;
     const uint32_t *sorted_count = nullptr;    // tile_ctl[kCtlSortedCount]
     uint32_t *ghist_now = nullptr, *ghist_next = nullptr;   // the ghost sort's digit histograms (kHistCopies copies, two sets)
+    // ghost lists (kGhostSlots ids per tile of the tile box): this step's, and the next step's counts to reset
+    uint32_t *gl_count = nullptr, *gl_entry = nullptr, *gl_count_next = nullptr;
+    uint32_t *ghost_sort = nullptr, *ghost_sort_next = nullptr;   // tile_ctl[kCtlGhostSort + parity], ... of the next step
 };
 constexpr int kHashBlock = 1024;
 constexpr int kHashBatch = 2;                  // positions loaded per lane before any of them is ranked
@@ -237,8 +246,8 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                                                             const uint32_t *__restrict__ sorted_key, uint32_t parity,
                                                             uint64_t div_magic, uint32_t *__restrict__ exc_count,
                                                             uint2 *__restrict__ exc_entry,
-                                                            uint32_t *__restrict__ exc_count_next, int32_t exc_tiles_x,
-                                                            int32_t exc_tiles_y, uint32_t straggler_limit, HashGhosts G)
+                                                            uint32_t *__restrict__ exc_count_next, TileBox tb,
+                                                            uint32_t straggler_limit, HashGhosts G)
 {
     // sorted_key[i] = the block key particle i had when the radix passes last ran (they keep it up to date,
     // k_onesweep.hip): the sorted ids and the block table still describe THAT grouping.  As long as every particle
@@ -265,9 +274,14 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.gtable_pairs; i += (uint64_t)gridDim.x * blockDim.x)
         G.gtable2[i] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);   // the ghosts' block table: rebuilt every step
     if (exc_count_next) {                                              // the next step's straggler lists
-        const uint64_t nt = (uint64_t)exc_tiles_x * (uint64_t)exc_tiles_y;
+        const uint64_t nt = (uint64_t)tb.nx * (uint64_t)tb.ny;
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (uint64_t)gridDim.x * blockDim.x)
             exc_count_next[i] = 0;
+    }
+    if (GHOSTS && G.gl_count_next) {                                   // ... and ghost lists
+        const uint64_t nt = (uint64_t)tb.nx * (uint64_t)tb.ny;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (uint64_t)gridDim.x * blockDim.x)
+            G.gl_count_next[i] = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < kCtlPerStepWords) {
         if (host_stat) {                                               // last step's statistics (kStat*), lagged
@@ -289,6 +303,8 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
             tile_ctl[kCtlNeedSort + (parity ^ 1u)] = 0;
             tile_ctl[kCtlFresh + (parity ^ 1u)] = 0;
             tile_ctl[parity ? kCtlStragglers0 : kCtlStragglers1] = 0;
+            if (GHOSTS && G.ghost_sort_next) *G.ghost_sort_next = 0u;
+            if (GHOSTS && G.gkeys && !G.gl_count) atomicOr(G.ghost_sort, 1u);   // (no lists: the ghosts are always sorted)
             if (!sorted_key) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
         }
     }
@@ -356,6 +372,18 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                     const uint64_t j = idx[u] - n_own;
                     if (j < G.g_bound) { G.gkeys[j] = key; G.gids[j] = (uint32_t)idx[u]; gkey = key; gvalid = true; }
                     key = pad_key;
+                    if (G.gl_count && !out) {
+                        // ... and listed for every tile whose window holds its cell (as the stragglers below)
+                        const int tx0 = max(tb.x0, (cx - (kConeRight + 1)) >> 5), tx1 = min(tb.x0 + tb.nx - 1, (cx + kConeLeft + 1) >> 5);
+                        const int ty0 = max(tb.y0, (cy - (kConeUp + 1)) >> 5), ty1 = min(tb.y0 + tb.ny - 1, (cy + kConeDown + 1) >> 5);
+                        for (int ty = ty0; ty <= ty1; ++ty)
+                            for (int tx = tx0; tx <= tx1; ++tx) {
+                                const uint32_t t = tb.index(tx, ty);
+                                const uint32_t slot = atomicAdd(&G.gl_count[t], 1u);
+                                if (slot < kGhostSlots) G.gl_entry[(uint64_t)t * kGhostSlots + slot] = (uint32_t)idx[u];
+                                else atomicOr(G.ghost_sort, 1u);       // a list ran over: the ghosts' sort runs this step
+                            }
+                    }
                 }
                 keys[idx[u]] = key;
                 // The particle's cell relative to the first cell of the block it was SORTED into: is it still within the
@@ -404,11 +432,11 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 if (straggler && route) {
                     // every 32x32 tile whose window [32 tx - 5, 32 tx + 35] x [32 ty - 3, 32 ty + 33] holds the cell
                     // (sub-tiles of the over-capacity launch read their parent's list: their windows lie inside its)
-                    const int tx0 = max(0, (cx - (kConeRight + 1)) >> 5), tx1 = min(exc_tiles_x - 1, (cx + kConeLeft + 1) >> 5);
-                    const int ty0 = max(0, (cy - (kConeUp + 1)) >> 5), ty1 = min(exc_tiles_y - 1, (cy + kConeDown + 1) >> 5);
+                    const int tx0 = max(tb.x0, (cx - (kConeRight + 1)) >> 5), tx1 = min(tb.x0 + tb.nx - 1, (cx + kConeLeft + 1) >> 5);
+                    const int ty0 = max(tb.y0, (cy - (kConeUp + 1)) >> 5), ty1 = min(tb.y0 + tb.ny - 1, (cy + kConeDown + 1) >> 5);
                     for (int ty = ty0; ty <= ty1; ++ty)
                         for (int tx = tx0; tx <= tx1; ++tx) {
-                            const uint32_t t = (uint32_t)(ty * exc_tiles_x + tx);
+                            const uint32_t t = tb.index(tx, ty);
                             const uint32_t slot = atomicAdd(&exc_count[t], 1u);
                             if (slot < kExcSlots) exc_entry[(uint64_t)t * kExcSlots + slot] = make_uint2((uint32_t)idx[u], (uint32_t)cx | ((uint32_t)cy << 16));
                             else { drifted = true; atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u); }   // a list ran over: sort (and tell the others)
@@ -524,7 +552,11 @@ struct CollideArgs {
     const uint32_t *gsorted_ids; // ... and their particle indices in that order
     const uint32_t *exc_count;   // stragglers handed to each 32x32 tile this step (NULL: none, the run always sorts)
     const uint2 *exc_entry;      // kExcSlots x (particle, cell x | y << 16) per tile
-    int32_t exc_tiles_x;
+    TileBox tb;                  // the tiles those lists, the ghost lists and the rosters are kept for
+    const uint32_t *gho_count;   // sharded runs: ghosts listed for each tile this step (NULL: none / not sharded)
+    const uint32_t *gho_entry;   // kGhostSlots x particle index per tile
+    const uint32_t *ghost_sort;  // tile_ctl[kCtlGhostSort + parity]: != 0 when a ghost list ran over this step -- the
+                                 // ghosts are then looked up in their block table (gtable) instead
     const uint32_t *fresh;       // tile_ctl[kCtlFresh + parity]: != 0 when the radix passes ran this step (the table is
                                  // of NOW: nobody is a straggler, the lists and the rosters are not used)
     const uint2 *table;
@@ -1212,7 +1244,15 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     const uint32_t fresh_word = *A.fresh;
     const uint32_t owned_word = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
     uint32_t exc_word = 0;
-    if (A.exc_count) exc_word = A.exc_count[(uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5)];
+    const int ptx = (tx * T) >> 5, pty = (ty * T) >> 5;                // the 32x32 parent tile (lists are kept per parent)
+    const bool in_tb = A.tb.holds(ptx, pty);
+    const uint32_t pt = in_tb ? A.tb.index(ptx, pty) : 0u;
+    if (A.exc_count && in_tb) exc_word = A.exc_count[pt];
+    uint32_t gho_word = 0, gsort_word = 0;
+    if constexpr (ORD) {
+        if (A.ghost_sort) gsort_word = *A.ghost_sort;
+        if (A.gho_count && in_tb) gho_word = A.gho_count[pt];
+    }
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
     S.cell_clear(tid);
@@ -1223,7 +1263,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         const int bx = box + bi, by = boy + bj;
         uint32_t start = 0, count = 0;
         const int lbx = bx - A.bx0, lby = by - A.by0;
-        const uint2 *tab = (ORD && tid >= NBLK) ? A.gtable : A.table;
+        // (the ghosts: through their block table only when a ghost list ran over this step, or there are no lists)
+        const bool ghosts_by_table = ORD && (A.gho_count == nullptr || __builtin_amdgcn_readfirstlane((int)gsort_word) != 0);
+        const uint2 *tab = (ORD && tid >= NBLK) ? (ghosts_by_table ? A.gtable : nullptr) : A.table;
         if (tab && lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
             const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
             if (mb < A.entries) {
@@ -1272,6 +1314,12 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;       // (listed under a block it is out of reach of: skipped)
     // stragglers handed to this tile's 32x32 parent by the hash kernel (P1 files them behind the looked-up particles)
     const uint32_t n_exc = stale ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)exc_word), kExcSlots) : 0u;
+    // ghosts listed for the tile's parent (sharded runs; none when the ghosts come through their block table this step)
+    uint32_t n_gho = 0;
+    if constexpr (ORD) {
+        if (A.gho_count != nullptr && __builtin_amdgcn_readfirstlane((int)gsort_word) == 0)
+            n_gho = min((uint32_t)__builtin_amdgcn_readfirstlane((int)gho_word), kGhostSlots);
+    }
     // Nothing of its own to write?  With the table of this step: no particle in the tile's own blocks.  With a kept
     // table a particle may have drifted up to kDrift* cells out of the block that lists it, so only an empty lookup
     // region (own blocks + the ring around them) AND an empty straggler list tell -- a straggler that flew into empty
@@ -1280,8 +1328,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     if constexpr (L::kGlobal) {
         // take a slice of the global spill arena for this tile's particle arrays
         if (tid == 0) {
-            const uint32_t base = atomicAdd(&A.tile_ctl[kCtlArena], P + kExcSlots);     // (+ the stragglers' slots)
-            const bool ok = (uint64_t)base + P + kExcSlots <= (uint64_t)A.arena_cap;
+            const uint32_t extra = kExcSlots + (ORD ? kGhostSlots : 0u);                 // (+ the stragglers' and the listed ghosts' slots)
+            const uint32_t base = atomicAdd(&A.tile_ctl[kCtlArena], P + extra);
+            const bool ok = (uint64_t)base + P + extra <= (uint64_t)A.arena_cap;
             S.misc[2] = ok ? 1u : 0u;
             S.px = A.arena_px + base; S.py = A.arena_py + base; S.rad = A.arena_rad + base;
             S.id = A.arena_id + base; S.hm = A.arena_hm + base; S.sblk = A.arena_sblk + base;
@@ -1415,7 +1464,6 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     if (n_exc != 0 && tid < 64) {                                      // (scalar condition; one wave files them)
         // Stragglers: particles out of reach of the block the table lists them under, handed over with their cell.
         const bool have = (uint32_t)tid < n_exc;
-        const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
         const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + (have ? (uint32_t)tid : 0u)];
         uint32_t pid = en.x;
         const float2 pp = A.pos_in[pid];
@@ -1455,11 +1503,55 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             }
         }
     }
+    if constexpr (ORD) {
+        // Ghosts listed for the tile's parent by the hash kernel: filed like the stragglers, placed by the cell in their
+        // code word (a listed ghost lies in the parent's window, so its cell mod 128 names one cell of this window or none).
+        for (uint32_t g0 = 0; g0 < n_gho; g0 += kNatThreads) {         // (scalar bounds: whole waves, the slots use ballots)
+            const uint32_t gi = g0 + (uint32_t)tid;
+            const bool have = gi < n_gho;
+            const uint32_t lidq = A.gho_entry[(uint64_t)pt * kGhostSlots + (have ? gi : 0u)];
+            const float2 pp = A.pos_in[lidq];
+            const float pr = A.radius[lidq];
+            const uint32_t cc = A.codes[lidq];
+            const uint32_t pid = A.order_keys[lidq];
+            const int lx = code_window_x(cc, ox), ly = code_window_y(cc, oy);
+            bool keep = have && lx < RWX && ly < RWY;
+            uint32_t sl = P + n_exc + gi;                               // the spill window: behind the stragglers
+            if constexpr (kTrim) {
+                const uint64_t mk = __ballot(keep);
+                uint32_t base = 0;
+                if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                sl = base + popc_below_lane(mk);
+                keep = keep && sl < (uint32_t)(sizeof(S.px) / sizeof(float));
+            } else if (have && !keep) {
+                S.px[sl] = pp.x; S.py[sl] = pp.y; S.rad[sl] = pr; S.id[sl] = pid;
+                S.cell_inc(0 + 1);
+                S.hm[sl] = 0u;
+            }
+            if (keep) {
+                S.px[sl] = pp.x; S.py[sl] = pp.y; S.rad[sl] = pr; S.id[sl] = pid;
+                if constexpr (L::kLid) S.lid[sl] = lidq;
+                const int home = (ly + 1) * PX + lx + 1;
+                S.cell_inc(home + 1);
+                uint32_t over = (cc >> kCodeOverlapShift) & 0xFFu;
+                const uint32_t own = (lx >= HX && lx < HX + T && ly >= HY && ly < HY + T) ? (1u << 19) : 0u;
+                S.hm[sl] = (uint32_t)home | (over << 11) | own;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (over == 0) break;
+                    const int k = __ffs((int)over) - 1;
+                    over &= over - 1u;
+                    S.cell_inc(home + neighbour_offset<PX>(k) + 1);
+                }
+            }
+        }
+    }
     __syncthreads();
     GPE_STAMP(1);
     // particles in the window from here on: the kept ones (the global window keeps every looked-up particle: its
-    // cell window is the looked-up blocks; the stragglers sit behind them)
-    uint32_t PS = P + (kTrim ? 0u : n_exc);
+    // cell window is the looked-up blocks; the stragglers and the listed ghosts sit behind them)
+    uint32_t PS = P + (kTrim ? 0u : n_exc + n_gho);
     if constexpr (kTrim) {
         PS = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[3]);
         if (PS > (uint32_t)(sizeof(S.px) / sizeof(float))) return false;    // more kept particles than the window stages
@@ -1739,10 +1831,11 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
             if constexpr (ORD) {                                       // S.id holds the order key: find the block of
                 const uint32_t raw = s;                                // the looked-up slot, re-read the local index
-                if (raw >= P) {
+                if (raw >= P + n_exc) {
+                    id = A.gho_entry[(uint64_t)pt * kGhostSlots + (raw - P - n_exc)];   // a listed ghost
+                } else if (raw >= P) {
                     // a straggler (filed behind the looked-up slots by P1): no block lists it -- its local index is
                     // the entry of the tile's straggler list it came from
-                    const uint32_t pt = (uint32_t)((ty * T) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((tx * T) >> 5);
                     id = A.exc_entry[(uint64_t)pt * kExcSlots + (raw - P)].x;
                 } else {
                     int lo = 0, hi = VB;
@@ -1824,8 +1917,9 @@ __device__ __forceinline__ void resolve_quarter(OverflowLds<ORD> &u, const Colli
                     if (own) A.pos_out[id] = A.pos_in[id];
                 }
             }
-            if (stale && A.exc_count) {
-                const uint32_t pt = (uint32_t)((sy * kTileSmall) >> 5) * (uint32_t)A.exc_tiles_x + (uint32_t)((sx * kTileSmall) >> 5);
+            const int qtx = (sx * kTileSmall) >> 5, qty = (sy * kTileSmall) >> 5;
+            if (stale && A.exc_count && A.tb.holds(qtx, qty)) {
+                const uint32_t pt = A.tb.index(qtx, qty);
                 const uint32_t ne = min(A.exc_count[pt], kExcSlots);
                 for (uint32_t e = threadIdx.x; e < ne; e += kNatThreads) {
                     const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + e];
@@ -1875,6 +1969,9 @@ struct TileDirect {
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
     uint8_t own[CAP];          // the particle's home cell lies in the tile
+    // member slots a zone cell owns: six; an order-key (sharded) window keeps a local index per particle as well and
+    // pays for it with the sixth slot (its cells of six members go to the side list and a wave, like cells of seven)
+    static constexpr int kMemSlots = LID ? kDirectSlots - 1 : kDirectSlots;
     uint32_t cntw[(NZ + 1) / 2];   // members per zone cell, two 16-bit counters per word (LDS atomics are 32 bit)
     __device__ __forceinline__ uint32_t cnt_inc(int i)                // returns the value before the add
     {
@@ -1884,7 +1981,7 @@ struct TileDirect {
     __device__ __forceinline__ uint32_t cnt_get(int i) const { return (cntw[i >> 1] >> ((uint32_t)(i & 1) * 16u)) & 0xFFFFu; }
     // members: kDirectSlots per zone cell, then 64 per wave for the cells gathered from the side list.  (Named like
     // TileLds' member array: the resolvers index S.mem[b + k].)
-    uint16_t mem[kDirectSlots * NZ + NW * 64];
+    uint16_t mem[kMemSlots * NZ + NW * 64];
     union {
         uint16_t list[4 * QZ]; // active cells, one segment per colour (P4 on)
         uint8_t sblk[RAWCAP];  // P0-P1 only: region block a looked-up slot came from
@@ -1893,7 +1990,7 @@ struct TileDirect {
     uint16_t wlist[4 * WC];    // cells of more than kDirectSlots members, per colour
     uint32_t big[kBigCap];     // memberships that found their cell's slots taken: zone cell << 16 | particle slot
     uint32_t lcnt[12];
-    static constexpr int VBMAX = kLid ? 2 * NBLK : NBLK;  // (see TileLds: owned and ghost lookups of an order-key window)
+    static constexpr int VBMAX = NBLK;                    // (an order-key window gets its ghosts from the tile's ghost list)
     uint32_t bstart[VBMAX];
     uint32_t bcnt[VBMAX];
     uint32_t boff[VBMAX + 1];
@@ -1906,9 +2003,10 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 {
     constexpr int TX = L::TX, TY = L::TY, NT = L::NT, NW = L::NW;
     constexpr int RWX = L::RWX, RWY = L::RWY, NBX = L::NBX, NBY = L::NBY, NBLK = L::NBLK, QMAX = L::QMAX;
-    constexpr int VB = ORD ? 2 * NBLK : NBLK;                          // (owned and ghost lookups: see process_tile)
-    static_assert(VB <= 255 && VB <= L::VBMAX, "sblk is 8 bit; the lookup arrays hold the virtual blocks");
+    constexpr int VB = NBLK;                                           // (the ghosts of an order-key window: from the ghost list)
+    static_assert(VB <= 255 && VB <= L::VBMAX, "sblk is 8 bit; the lookup arrays hold the blocks");
     constexpr int ZX = L::ZX, ZY = L::ZY, NZ = L::NZ, QZ = L::QZ;
+    constexpr int MS = L::kMemSlots;
     constexpr int HX = L::HXL, HY = L::HYL;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -1919,20 +2017,27 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     const uint32_t owned_word = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
     // stragglers handed to this tile by the hash kernel
     static_assert(TY == 32 && TX == 32, "straggler lists and rosters are kept per 32x32 tile");
-    const uint32_t exc_word = A.exc_count ? A.exc_count[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx] : 0u;
+    const bool in_tb = A.tb.holds(tx, ty);                             // (always, for the tiles of the dense launch)
+    const uint32_t pt = in_tb ? A.tb.index(tx, ty) : 0u;
+    const uint32_t exc_word = (A.exc_count && in_tb) ? A.exc_count[pt] : 0u;
+    uint32_t gho_word = 0, gsort_word = 0;
+    if constexpr (ORD) {
+        if (A.ghost_sort) gsort_word = *A.ghost_sort;
+        if (A.gho_count && in_tb) gho_word = A.gho_count[pt];
+    }
     // the tile's roster (CollideArgs): header, and the first ids on the chance that it is valid
-    constexpr bool kRoster = !ORD && TX == 32 && NT == 512;
+    constexpr bool kRoster = TX == 32 && NT == 512;
     constexpr int QP = QMAX >= 2 ? 2 : 1;
     static_assert(!kRoster || L::RAWCAP == kRosterCap, "roster stride");
-    const bool rosters = kRoster && A.roster_hdr != nullptr;
-    const uint64_t roster_base = (uint64_t)((uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx) * (uint64_t)kRosterCap;
+    const bool rosters = kRoster && A.roster_hdr != nullptr && in_tb;
+    const uint64_t roster_base = (uint64_t)pt * (uint64_t)kRosterCap;
     uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
     uint32_t sorts_word = 0;
     uint32_t first_ids[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) first_ids[q] = 0u;
     if (rosters) {
-        hdr = A.roster_hdr[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx];
+        hdr = A.roster_hdr[pt];
         sorts_word = *A.sorts_seen;
 #pragma unroll
         for (int q = 0; q < QP; ++q) first_ids[q] = A.roster_ids[roster_base + (uint32_t)tid + (uint32_t)q * NT];
@@ -1942,6 +2047,12 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     for (int i = tid; i < (NZ + 1) / 2; i += NT) S.cntw[i] = 0;
     if (tid < 12) S.lcnt[tid] = 0;
     const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
+    if constexpr (ORD) {
+        // a ghost list ran over this step: the ghosts come through their block table, which only the counting-sort
+        // windows of the over-capacity launch look up -- hand the tile on (a crowded border; the host's `crowded` policy
+        // moves such scenes to those windows altogether)
+        if (A.gho_count == nullptr || __builtin_amdgcn_readfirstlane((int)gsort_word) != 0) return false;
+    }
     const uint32_t stamp_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorts_word) + 1u;
     // (scalar) the roster is of the table in use: no lookup
     const bool listed = rosters && stale && (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y) == stamp_now;
@@ -1961,7 +2072,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         const int bi = rb % NBX, bj = rb / NBX;
         const int lbx = box + bi - A.bx0, lby = boy + bj - A.by0;
         uint32_t start = 0, count = 0;
-        const uint2 *tab = (ORD && tid >= NBLK) ? A.gtable : A.table;
+        const uint2 *tab = A.table;
         if (tab && lbx >= 0 && lby >= 0 && lbx < A.blocks_x && lby < A.blocks_y) {
             const uint32_t mb = (uint32_t)(lby * A.blocks_x + lbx);
             if (mb < A.entries) {
@@ -1988,7 +2099,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             const int bi = lane % NBX, bj = lane / NBX;
             const bool own_blk = lane < NBLK && bi >= 1 && bi < NBX - 1 && bj >= 1 && bj < NBY - 1;
             uint32_t v = 0;
-            if (own_blk) v = S.bcnt[lane] + (ORD ? S.bcnt[lane + NBLK] : 0u);
+            if (own_blk) v = S.bcnt[lane];
             const uint32_t own = wave_sum(v);                          // (all 64 lanes of wave 0 take part)
             if (lane == 0) S.misc[1] = own;
         }
@@ -2009,10 +2120,11 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     const uint32_t n_owned = (uint32_t)__builtin_amdgcn_readfirstlane((int)owned_word);
     const uint32_t straggler_bit = stale ? kCodeStraggler : 0u;
     const uint32_t n_exc = stale ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)exc_word), kExcSlots) : 0u;
+    const uint32_t n_gho = ORD ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)gho_word), kGhostSlots) : 0u;   // listed ghosts
     if (record && tid == 0) {
         // the header of the roster the gather below writes (an empty lookup is a valid, empty roster)
         const uint32_t count = P > (uint32_t)L::RAWCAP ? 0xFFFFFFFFu : P;
-        A.roster_hdr[(uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx] = make_uint4(count, stamp_now, S.misc[5], 0u);
+        A.roster_hdr[pt] = make_uint4(count, stamp_now, S.misc[5], 0u);
     }
     {
         // nothing of its own to write?  (see process_tile: own blocks with the table of this step; the whole lookup
@@ -2041,7 +2153,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         if ((unsigned)zx < (unsigned)ZX && (unsigned)zy < (unsigned)ZY) {
             const int zc = zy * ZX + zx;
             const uint32_t k = S.cnt_inc(zc);
-            if (k < (uint32_t)kDirectSlots) S.mem[zc * kDirectSlots + (int)k] = (uint16_t)s;
+            if (k < (uint32_t)MS) S.mem[zc * MS + (int)k] = (uint16_t)s;
             else {
                 const uint32_t e = atomicAdd(&S.misc[4], 1u);
                 if (e < (uint32_t)kBigCap) S.big[e] = ((uint32_t)zc << 16) | s;
@@ -2087,8 +2199,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         for (int q = 0; q < QP; ++q) {                                 // branch-free, all loads in flight: see process_tile
             const uint32_t s = min(s0 + (uint32_t)tid + (uint32_t)q * NT, P - 1u);
             blk[q] = S.sblk[s];
-            const uint32_t *ids = (ORD && blk[q] >= (uint32_t)NBLK) ? A.gsorted_ids : A.sorted_ids;
-            pid[q] = ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
+            pid[q] = A.sorted_ids[S.bstart[blk[q]] + (s - S.boff[blk[q]])];
         }
         if (record) {
 #pragma unroll
@@ -2122,7 +2233,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             lxq[q] = code_window_x(cc[q], ox);
             lyq[q] = code_window_y(cc[q], oy);
             keep[q] = s < P && lxq[q] < RWX && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
-            if constexpr (ORD) keep[q] = keep[q] && (A.gtable == nullptr || blk[q] >= (uint32_t)NBLK || lidq[q] < n_owned);   // (see process_tile)
+            // (an order-key window: the kept table -- or the roster written from it -- may still list indices the owned
+            // range has shrunk below: those particles are ghosts now, or gone; they come through the ghost list, or not at all)
+            if constexpr (ORD) keep[q] = keep[q] && lidq[q] < n_owned;
             mq[q] = __ballot(keep[q]);
             cnt += (uint32_t)__popcll(mq[q]);
         }
@@ -2141,7 +2254,6 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     }
     if (n_exc != 0 && tid < 64) {                                      // stragglers handed to the tile (see process_tile)
         const bool have = (uint32_t)tid < n_exc;
-        const uint32_t pt = (uint32_t)ty * (uint32_t)A.exc_tiles_x + (uint32_t)tx;
         const uint2 en = A.exc_entry[(uint64_t)pt * kExcSlots + (have ? (uint32_t)tid : 0u)];
         uint32_t pid = en.x;
         const float2 pp = A.pos_in[pid];
@@ -2158,6 +2270,27 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         const uint32_t sl = base + popc_below_lane(mk);
         keep = keep && sl < (uint32_t)L::kSlots;
         if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, (cc >> kCodeOverlapShift) & 0xFFu);
+    }
+    if constexpr (ORD) {
+        // ghosts listed for the tile by the hash kernel (see process_tile)
+        for (uint32_t g0 = 0; g0 < n_gho; g0 += (uint32_t)NT) {        // (scalar bounds: whole waves, the slots use ballots)
+            const uint32_t gi = g0 + (uint32_t)tid;
+            const bool have = gi < n_gho;
+            const uint32_t lidq = A.gho_entry[(uint64_t)pt * kGhostSlots + (have ? gi : 0u)];
+            const float2 pp = A.pos_in[lidq];
+            const float pr = A.radius[lidq];
+            const uint32_t cc = A.codes[lidq];
+            const uint32_t pid = A.order_keys[lidq];
+            const int lx = code_window_x(cc, ox), ly = code_window_y(cc, oy);
+            bool keep = have && lx < RWX && ly < RWY;
+            const uint64_t mk = __ballot(keep);
+            uint32_t base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t sl = base + popc_below_lane(mk);
+            keep = keep && sl < (uint32_t)L::kSlots;
+            if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, (cc >> kCodeOverlapShift) & 0xFFu);
+        }
     }
     __syncthreads();
     GPE_STAMP(1);
@@ -2230,8 +2363,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                                      eyr <= kConeUp - (c >> 1);
                 const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
                 const bool act = (cnt[c] >= 2) && !unused_alias && in_zone;
-                group[c] = act && cnt[c] >= kGroupMin && cnt[c] <= (uint32_t)kDirectSlots;
-                bool wavec = act && cnt[c] > (uint32_t)kDirectSlots;
+                group[c] = act && cnt[c] >= kGroupMin && cnt[c] <= (uint32_t)MS;
+                bool wavec = act && cnt[c] > (uint32_t)MS;
                 if (wavec) {
                     if (cnt[c] > 64u) S.misc[2] = 1u;                  // a pile: the sub-tile windows resolve those
                     const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
@@ -2278,13 +2411,13 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #endif
             if (i < group_lanes) {
                 const uint32_t en = S.list[k * QZ + (QZ - 1) - (i / kGroupLanes)];
-                resolve_group(S, (en & 0xFFFu) * kDirectSlots, (en >> 12) + kGroupMin, (int)(i % kGroupLanes), A.stiffness);
+                resolve_group(S, (en & 0xFFFu) * MS, (en >> 12) + kGroupMin, (int)(i % kGroupLanes), A.stiffness);
             } else if (i >= single_base && (i & ~63u) < work) {         // (whole waves: the walk uses ballots)
                 const bool on = i < work;
                 uint32_t b = 0, n = 0;
                 if (on) {
                     const uint32_t en = S.list[k * QZ + (i - single_base)];
-                    b = (en & 0xFFFu) * kDirectSlots; n = 2u + (en >> 12);
+                    b = (en & 0xFFFu) * MS; n = 2u + (en >> 12);
                 }
                 resolve_small_cells(S, on, b, n, A.stiffness);
             }
@@ -2294,9 +2427,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             // scratch run of the member array; then the whole-wave walk
             const uint32_t zc = S.wlist[k * L::WC + i];
             const uint32_t n = S.cnt_get((int)zc);
-            const uint32_t wb = (uint32_t)(kDirectSlots * NZ) + (uint32_t)(tid >> 6) * 64u;
-            if (lane < kDirectSlots) S.mem[wb + lane] = S.mem[zc * kDirectSlots + lane];
-            uint32_t filled = kDirectSlots;
+            const uint32_t wb = (uint32_t)(MS * NZ) + (uint32_t)(tid >> 6) * 64u;
+            if (lane < MS) S.mem[wb + lane] = S.mem[zc * MS + lane];
+            uint32_t filled = MS;
             for (uint32_t e0 = 0; e0 < n_big; e0 += 64u) {
                 const uint32_t e = e0 + (uint32_t)lane;
                 const uint32_t v = e < n_big ? S.big[e] : 0xFFFFFFFFu;
@@ -2319,17 +2452,24 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #ifdef GPE_DBG_SKIP
         if (GPE_DBG_SKIP & 32) continue;
 #endif
+        if (q >= 1 && PS <= (uint32_t)q * NT) continue;                  // (scalar, as where own_id was filled)
         const uint32_t id = own_id[q];
-        if (id == 0xFFFFFFFFu) continue;
-        const uint32_t s = (uint32_t)tid + (uint32_t)q * NT;
+        const bool have = id != 0xFFFFFFFFu;
+        const uint32_t s = min((uint32_t)tid + (uint32_t)q * NT, (uint32_t)L::kSlots - 1u);
         const float2 c = make_float2(S.px[s], S.py[s]);
-        if (A.fuse_verlet && id < n_owned) {
-            float2 o;
-            verlet_one(c.x, c.y, own_prev[q].x, own_prev[q].y, S.rad[s], A.vp, o.x, o.y);
+        const float rr = S.rad[s];
+        float2 o = c;
+        const bool mine = have && A.fuse_verlet && id < n_owned;
+        if (mine) {
+            verlet_one(c.x, c.y, own_prev[q].x, own_prev[q].y, rr, A.vp, o.x, o.y);
             A.prev[id] = c;
             A.pos_out[id] = o;
-        } else {
+        } else if (have) {
             A.pos_out[id] = c;
+        }
+        if constexpr (ORD) {
+            // a sharded step: the tiles pack their own particles for the neighbours (S.id holds the order key)
+            if (A.pack.on) pack_if_near_border(A.pack, mine, id, o, c, rr, S.id[s], A.cell_size);
         }
     }
     __syncthreads();
@@ -2339,6 +2479,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 
 #ifndef GPE_CAP_DIRECT
 #define GPE_CAP_DIRECT 928
+#endif
+#ifndef GPE_CAP_DIRECT_ORD
+#define GPE_CAP_DIRECT_ORD 880                 // order-key windows: 21 B per particle instead of 17, five member slots per cell
 #endif
 // 32 x 32-cell tiles on 512 threads, four workgroups per CU.  A tile the window has no room for is listed for
 // k_collide_overflow.  (64 x 32-cell tiles on 1024 threads -- two per CU, the window 1.32 x the tile's own cells instead of
@@ -2434,6 +2577,7 @@ void native_release(gpe_ctx *c)
     if (N.codes) (void)hipFree(N.codes);
     if (N.sorted_key) (void)hipFree(N.sorted_key);
     if (N.exc_count) (void)hipFree(N.exc_count);
+    if (N.gho_count) (void)hipFree(N.gho_count);
     if (N.roster_hdr) (void)hipFree(N.roster_hdr);
     if (N.roster_ids) (void)hipFree(N.roster_ids);
     if (N.gkeys) (void)hipFree(N.gkeys);
@@ -2522,6 +2666,13 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         hg.ghist_now = N.ghist + (size_t)N.ghist_set * kHistSet;       // (two sets, alternating over the steps that use them:
         hg.ghist_next = N.ghist + (size_t)(N.ghist_set ^ 1u) * kHistSet;   //  this step's hash zeroes the next one's)
         N.ghist_set ^= 1u;
+        hg.ghost_sort = N.tile_ctl + kCtlGhostSort + parity;
+        hg.ghost_sort_next = N.tile_ctl + kCtlGhostSort + (parity ^ 1u);
+        if (N.gho_count && N.gho_cap >= N.exc_tiles) {                 // ghost lists: two sets by step parity, like the stragglers'
+            hg.gl_count = N.gho_count + (size_t)parity * N.exc_tiles;
+            hg.gl_count_next = N.gho_count + (size_t)(parity ^ 1u) * N.exc_tiles;
+            hg.gl_entry = N.gho_count + 2 * N.exc_tiles + (size_t)parity * N.exc_tiles * kGhostSlots;
+        }
     }
     {
         Scope s(c, "native/hash");
@@ -2537,7 +2688,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
                            N.host_stat, reuse ? N.sorted_key : nullptr, parity, div_magic,
                            N.exc_count ? N.exc_count + (size_t)parity * N.exc_tiles : nullptr,
                            N.exc_count ? N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots : nullptr,
-                           N.exc_count ? N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles : nullptr, N.exc_tiles_x, N.exc_tiles_y,
+                           N.exc_count ? N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles : nullptr, N.tb,
                            (uint32_t)std::max<uint64_t>(64, n >> 11),       // more stragglers than 0.05 % of the particles: sort
                            hg);
         GPE_HIP(c, hipGetLastError());
@@ -2568,8 +2719,9 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         // pass fills the ghosts' block table
         Scope s(c, "shard/ghost-sort");
         uint32_t *gk = nullptr, *gv = nullptr;
-        OnesweepGate gg;                                               // (not gated; its own tile tickets)
-        gg.ticket_base = 8;
+        OnesweepGate gg;                                               // (its own tile tickets; runs when a ghost list ran over,
+        gg.ticket_base = 8;                                            //  or always when there are no lists)
+        gg.need = hg.ghost_sort;
         GPE_TRY(onesweep_sort(c, N.gkeys, N.gids, N.gkeys_b, N.gids_b, g_bound, N.passes, true, false, &gk, &gv, true,
                               N.gtable, N.table_entries, hg.ghist_now, &gg));
         (void)gk;
@@ -2578,6 +2730,9 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     N.sort_state_valid = gated;           // (the passes of this call ran, or the kept state was and stays valid)
     N.sorted_n = n;
     N.fresh_word = N.tile_ctl + kCtlFresh + parity;
+    N.gho_count_now = hg.gl_count;
+    N.gho_entry_now = hg.gl_entry;
+    N.ghost_sort_now = hg.ghost_sort;
     N.exc_count_now = reuse ? N.exc_count + (size_t)parity * N.exc_tiles : nullptr;
     N.exc_entry_now = reuse ? N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots : nullptr;
     *sorted_ids = sv;
@@ -2678,9 +2833,17 @@ gpe_status native_configure(gpe_ctx *c)
     const uint64_t tiles = (uint64_t)((N.gx + kTileMain - 1) / kTileMain) * ((N.gy + kTileMain - 1) / kTileMain);
     {
         // straggler lists: per 32x32 tile of the cell box a count and kExcSlots entries, two sets (step parity)
-        N.exc_tiles_x = (N.gx + 31) / 32;
-        N.exc_tiles_y = (N.gy + 31) / 32;
-        N.exc_tiles = (uint64_t)N.exc_tiles_x * (uint64_t)N.exc_tiles_y;
+        // the tile box: the whole cell box, or a sharded rank's active box
+        N.tb.x0 = 0; N.tb.y0 = 0; N.tb.nx = (N.gx + 31) / 32; N.tb.ny = (N.gy + 31) / 32;
+        if (c->has_active_box) {
+            const int32_t cx0 = std::max(0, c->active_box[0]), cy0 = std::max(0, c->active_box[1]);
+            const int32_t cx1 = std::min(N.gx - 1, c->active_box[2]), cy1 = std::min(N.gy - 1, c->active_box[3]);
+            if (cx1 >= cx0 && cy1 >= cy0) {
+                N.tb.x0 = cx0 / 32; N.tb.y0 = cy0 / 32;
+                N.tb.nx = cx1 / 32 - N.tb.x0 + 1; N.tb.ny = cy1 / 32 - N.tb.y0 + 1;
+            }
+        }
+        N.exc_tiles = (uint64_t)N.tb.nx * (uint64_t)N.tb.ny;
         if (N.exc_cap < N.exc_tiles) {
             if (N.exc_count) GPE_HIP(c, hipFree(N.exc_count));
             N.exc_count = nullptr; N.exc_entry = nullptr; N.exc_cap = 0;
@@ -2704,7 +2867,17 @@ gpe_status native_configure(gpe_ctx *c)
         GPE_HIP(c, hipFree(N.roster_hdr)); GPE_HIP(c, hipFree(N.roster_ids));
         N.roster_hdr = nullptr; N.roster_ids = nullptr; N.roster_cap = 0;
     }
-    if (!c->shard.on && rosters_pay && N.exc_count &&
+    if (c->shard.on && c->has_active_box && N.gho_cap < N.exc_tiles) {
+        // ghost lists (sharded runs): a count and kGhostSlots ids per tile, two sets.  Optional: without them the ghosts
+        // are sorted into their block table every step
+        if (N.gho_count) GPE_HIP(c, hipFree(N.gho_count));
+        N.gho_count = nullptr; N.gho_cap = 0;
+        if (hipMalloc((void **)&N.gho_count, 2 * N.exc_tiles * (1 + (size_t)kGhostSlots) * sizeof(uint32_t) + 64) == hipSuccess)
+            N.gho_cap = N.exc_tiles;
+        else { (void)hipGetLastError(); N.gho_count = nullptr; }
+    }
+    if (N.gho_count) GPE_HIP(c, hipMemsetAsync(N.gho_count, 0, 2 * N.exc_tiles * sizeof(uint32_t), c->stream));
+    if (rosters_pay && N.exc_count &&
         (c->cfg.flags & (GPE_FLAG_SORT_EVERY_STEP | GPE_FLAG_COUNTING_SORT_TILES)) == 0) {
         // tile rosters (CollideArgs): 16 + 4 kRosterCap bytes per 32x32 tile.  Optional: a device that has no room for
         // them runs without (every step then looks its blocks up)
@@ -2889,7 +3062,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.gsorted_ids = N.gsorted_ids_now;
     A.exc_count = N.exc_count_now;
     A.exc_entry = N.exc_entry_now;
-    A.exc_tiles_x = N.exc_tiles_x;
+    A.tb = N.tb;
+    A.gho_count = N.gsorted_ids_now ? N.gho_count_now : nullptr;     // (kept sharded run with ghosts this step)
+    A.gho_entry = N.gho_entry_now;
+    A.ghost_sort = N.ghost_sort_now;
     A.roster_hdr = (N.roster_cap >= N.exc_tiles) ? N.roster_hdr : nullptr;
     A.roster_ids = N.roster_ids;
     A.sorts_seen = N.tile_ctl + kCtlSortsSeen;
@@ -2979,12 +3155,17 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
                 if (N.calm_steps >= 64) N.crowded = false;
             }
         }
-        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || A.order_keys != nullptr || N.crowded;
+        // (order-key windows: the direct form needs the ghost lists of a kept sharded run; every other sharded set-up
+        // looks its ghosts up in the block tables, which only the counting-sort form does)
+        const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || N.crowded ||
+                            (A.order_keys != nullptr && A.gho_count == nullptr);
         if (legacy) {
             if (A.order_keys)
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
             else
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
+        } else if (A.order_keys) {
+            hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         } else {
             hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         }
