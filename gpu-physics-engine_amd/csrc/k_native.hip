@@ -372,18 +372,6 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                     const uint64_t j = idx[u] - n_own;
                     if (j < G.g_bound) { G.gkeys[j] = key; G.gids[j] = (uint32_t)idx[u]; gkey = key; gvalid = true; }
                     key = pad_key;
-                    if (G.gl_count && !out) {
-                        // ... and listed for every tile whose window holds its cell (as the stragglers below)
-                        const int tx0 = max(tb.x0, (cx - (kConeRight + 1)) >> 5), tx1 = min(tb.x0 + tb.nx - 1, (cx + kConeLeft + 1) >> 5);
-                        const int ty0 = max(tb.y0, (cy - (kConeUp + 1)) >> 5), ty1 = min(tb.y0 + tb.ny - 1, (cy + kConeDown + 1) >> 5);
-                        for (int ty = ty0; ty <= ty1; ++ty)
-                            for (int tx = tx0; tx <= tx1; ++tx) {
-                                const uint32_t t = tb.index(tx, ty);
-                                const uint32_t slot = atomicAdd(&G.gl_count[t], 1u);
-                                if (slot < kGhostSlots) G.gl_entry[(uint64_t)t * kGhostSlots + slot] = (uint32_t)idx[u];
-                                else atomicOr(G.ghost_sort, 1u);       // a list ran over: the ghosts' sort runs this step
-                            }
-                    }
                 }
                 keys[idx[u]] = key;
                 // The particle's cell relative to the first cell of the block it was SORTED into: is it still within the
@@ -451,6 +439,25 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 for (int q = 0; q < 4; ++q)
                     if (q < digits) hist_add(s_ghist + q * 256, (gkey >> (8 * q)) & 255u, gvalid);
             }
+        }
+    }
+    if (GHOSTS && G.gl_count) {
+        // The ghosts once more, for the tiles: every ghost is listed for each 32x32 tile whose window holds its cell (as
+        // the stragglers above).  A loop of its own over the few thousand ghosts -- inside the particle loop the routing
+        // pushed the kernel over its 64 registers.
+        for (uint64_t i = n_own + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+            const float2 p = pos[i];
+            const int32_t cx = cell_coord(p.x, cell_size), cy = cell_coord(p.y, cell_size);
+            if ((cx < 0) | (cx >= gx) | (cy < 0) | (cy >= gy)) continue;
+            const int tx0 = max(tb.x0, (cx - (kConeRight + 1)) >> 5), tx1 = min(tb.x0 + tb.nx - 1, (cx + kConeLeft + 1) >> 5);
+            const int ty0 = max(tb.y0, (cy - (kConeUp + 1)) >> 5), ty1 = min(tb.y0 + tb.ny - 1, (cy + kConeDown + 1) >> 5);
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const uint32_t t = tb.index(tx, ty);
+                    const uint32_t slot = atomicAdd(&G.gl_count[t], 1u);
+                    if (slot < kGhostSlots) G.gl_entry[(uint64_t)t * kGhostSlots + slot] = (uint32_t)i;
+                    else atomicOr(G.ghost_sort, 1u);                   // a list ran over: the ghosts' sort runs this step
+                }
         }
     }
     if (GHOSTS && G.gkeys && blockIdx.x == 0 && threadIdx.x < (uint32_t)digits) {
