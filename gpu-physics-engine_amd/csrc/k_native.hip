@@ -819,10 +819,23 @@ __device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint3
 // denormal / special-case steps and with one shared reciprocal for the two divisions -- 11 wave instructions
 // fewer per pair, same bits, 2 % SLOWER: the passes are bound by the dependent chain, not by issue slots.)
 // Returns the wave-uniform "some lane collided"; (p1, p2) are updated in place for lanes that collide.
+#ifdef GPE_COUNT_PAIRS
+// diagnostic builds only (scripts/soak_pairs.py): pairs the colour passes walk / resolve, over all tiles (the halo cells a
+// tile recomputes for its neighbours included) -- what "ms per 10^9 pairs" in BASELINE.md is measured with
+__device__ unsigned long long g_pairs_walked, g_pairs_hit;
+__device__ __forceinline__ void count_pairs(unsigned long long *ctr, const bool on)
+{
+    const uint64_t m = __ballot(on);
+    if (m != 0 && lane_id() == (int)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__popcll(m));
+}
+#endif
 __device__ __forceinline__ bool pair_response(const bool active, float &p1x, float &p1y, float &p2x, float &p2y,
                                               const float r1, const float r2, const bool r1_plain,
                                               const float stiffness, bool &hit)
 {
+#ifdef GPE_COUNT_PAIRS
+    count_pairs(&g_pairs_walked, active);
+#endif
     const float vx = p1x - p2x, vy = p1y - p2y;                       // :91 (live positions, :86)
     const float q = vx * vx + vy * vy;
     const float radius_sum = r1 + r2;                                 // :61
@@ -886,6 +899,9 @@ __device__ __forceinline__ bool pair_response(const bool active, float &p1x, flo
     const float n2x = p2x - cx * w2, n2y = p2y - cy * w2;             // :111
     p1x = hit ? n1x : p1x; p1y = hit ? n1y : p1y;
     p2x = hit ? n2x : p2x; p2y = hit ? n2y : p2y;
+#ifdef GPE_COUNT_PAIRS
+    count_pairs(&g_pairs_hit, hit);
+#endif
     return __ballot(hit) != 0;
 }
 
@@ -3259,3 +3275,22 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
 }
 
 }  // namespace gpe
+
+#ifdef GPE_COUNT_PAIRS
+// diagnostic builds only: (pairs walked, pairs resolved) since the last reset
+extern "C" gpe_status gpe_debug_pair_counts(gpe_ctx *c, uint64_t *out2, int32_t reset)
+{
+    if (!c || !out2) return GPE_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    unsigned long long w = 0, h = 0;
+    (void)hipMemcpyFromSymbol(&w, HIP_SYMBOL(gpe::g_pairs_walked), sizeof(w));
+    (void)hipMemcpyFromSymbol(&h, HIP_SYMBOL(gpe::g_pairs_hit), sizeof(h));
+    out2[0] = w; out2[1] = h;
+    if (reset) {
+        w = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_pairs_walked), &w, sizeof(w));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_pairs_hit), &w, sizeof(w));
+    }
+    return GPE_OK;
+}
+#endif
