@@ -97,6 +97,15 @@ __device__ __forceinline__ bool is_obj_in_cell(float px, float py, float sq_radi
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// The lanes of the wave for which `p` holds, as a mask.  (The builtin on the predicate itself: HIP's __ballot(int) turns
+// the lane mask the compare has just produced into a 0 / 1 register and compares that again -- two VALU instructions per
+// vote, and the tile kernels vote ~40 times per workgroup pass.)
+__device__ __forceinline__ uint64_t ballot64(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// ... and back: the per-lane predicate of a (wave-uniform) lane mask.  Costs nothing: selects and branches take the
+// mask as it is.  Votes on single comparisons combined by scalar ANDs, turned back into a predicate here, replace
+// `a && b && c` where the combined predicate is also voted on (pair_response, k_native.hip).
+__device__ __forceinline__ bool lanes_of(const uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // number of set bits of `m` strictly below this lane
 __device__ __forceinline__ uint32_t popc_below_lane(uint64_t m)
 {
@@ -173,11 +182,11 @@ __device__ __forceinline__ void hist_add(uint32_t *s_hist, uint32_t d, bool vali
     // digit value -- one atomic -- or every lane issues its own fire-and-forget LDS atomic (the LDS
     // serialises lanes that hit the same bin; measured cheaper than peeling the values off with ballots:
     // the hash kernel went from 0.44 to 0.70 ms at 100 M particles with a four-value peel).
-    const uint64_t m = __ballot(valid);
+    const uint64_t m = ballot64(valid);
     if (m == 0) return;                                        // wave-uniform
     const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
-    if (__ballot(valid && d != d0) == 0) {
+    if (ballot64(valid && d != d0) == 0) {
         if (lane_id() == first) atomicAdd(&s_hist[d0], (uint32_t)__popcll(m));
         return;
     }
@@ -351,7 +360,7 @@ constexpr int kMigWords = 6, kGhoWords = 4;      // migrant row: x y prev_x prev
 // rows of one (slot, kind): a wave-aggregated append; every lane of the wave must call it
 __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
 {
-    const uint64_t m = __ballot(want);
+    const uint64_t m = ballot64(want);
     if (m == 0) return 0xFFFFFFFFu;
     const int leader = (int)__builtin_ctzll(m);
     uint32_t base = 0;
@@ -396,7 +405,7 @@ __device__ __forceinline__ void pack_particle(const PackArgs &P, const bool mine
         gho = P.dest_mask[b] & 0x03FFFFFFu;             // ranks within one block of b, its owner excluded
         if (owner != P.my_rank) mig = (int)owner;       // b's owner takes the particle over
     }
-    if (__ballot(gho != 0 || mig >= 0) == 0) return;    // interior wave
+    if (ballot64(gho != 0 || mig >= 0) == 0) return;    // interior wave
     uint32_t err = 0;
     {
         const uint32_t h = wave_append(&P.counts[kShardHoles], mig >= 0);

@@ -216,8 +216,8 @@ __global__ __launch_bounds__(kStreamBlock) void k_ctl_block_hist(const uint32_t 
         // run heads inside the wave: a lane whose left neighbour (lane - 1) holds another block, or lane 0
         const uint32_t left = (uint32_t)__shfl_up((int)mb, 1, 64);
         const bool head = in && (lane_id() == 0 || left != mb);
-        const uint64_t heads = __ballot(head);
-        const uint64_t valid = __ballot(in);
+        const uint64_t heads = ballot64(head);
+        const uint64_t valid = ballot64(in);
         if (head) {
             // members of this run inside the wave: up to the next head (or the end of the valid lanes)
             const uint64_t above = heads & ~((2ull << lane_id()) - 1ull);

@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "gpe_internal.h"
 
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                 // counter, up to four per particle on the lists -- took longer than the tiles (100 M soak, step 1000:
                 // 22 ms/step with them, 16 without).  A wave learns it from the counter itself (its own add comes back
                 // above the limit) or from its workgroup (an LDS word): no extra global round trip in calm scenes.
-                const uint64_t ms = __ballot(straggler);
+                const uint64_t ms = ballot64(straggler);
                 bool route = false;
                 if (ms != 0 && !sort_known) {                            // (wave-uniform)
                     sort_known = wave_lds_load(&s_sort_known) != 0u;     // (another wave of the workgroup has learnt it)
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
         atomicAdd(&s_ghist[threadIdx.x * 256 + ((pad_key >> (8 * threadIdx.x)) & 255u)], (uint32_t)(G.g_bound - ng));
     }
     if (oob) atomicOr(&tile_ctl[kCtlError], kErrOutOfBox);
-    if (__ballot(drifted) != 0 && lane_id() == 0) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
+    if (ballot64(drifted) != 0 && lane_id() == 0) atomicOr(&tile_ctl[kCtlNeedSort + parity], 1u);
     __syncthreads();
     // Flush: fire-and-forget device-scope atomics (the kernel boundary makes them visible); the radix passes turn the
     // histograms into digit bases themselves (k_os_pass, hist_src), so no workgroup waits for the others here.
@@ -613,7 +614,7 @@ __device__ __forceinline__ void pack_if_near_border(const PackArgs &P, const boo
                                                     const float2 c, const float rad, const uint32_t key, const float cell_size)
 {
     const bool near = mine && (o.x < P.safe_x0 || o.x >= P.safe_x1 || o.y < P.safe_y0 || o.y >= P.safe_y1);
-    if (__ballot(near) == 0) return;
+    if (ballot64(near) == 0) return;
     pack_particle(P, near, id, o, c, rad, key, cell_size);
 }
 constexpr int kRosterCap = GPE_QMAX_MAIN_VALUE * 512;   // == TileDirect<32, .., 512>::RAWCAP
@@ -815,38 +816,55 @@ __device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint3
 //  * q = vx*vx + vy*vy > 1.000001 rs^2 implies rs^2 <= distance^2 (distance = sqrt(q) correctly rounded, so
 //    distance^2 >= q (1 - 2^-22)): no collision (:95); q < 9.9e-9 implies distance < 0.0001 (:95; 0.0001f squared
 //    is 9.99999995e-9): no collision either.  Neither needs the square root.
-// sqrtf and '/' are hipcc's correctly rounded sequences.  (Measured and dropped: the same sequences without their
-// denormal / special-case steps and with one shared reciprocal for the two divisions -- 11 wave instructions
-// fewer per pair, same bits, 2 % SLOWER: the passes are bound by the dependent chain, not by issue slots.)
-// Returns the wave-uniform "some lane collided"; (p1, p2) are updated in place for lanes that collide.
+//  * the correctly rounded square root and quotients without the steps hipcc's sequences spend on operands that
+//    cannot occur here (below).
+// Instruction budget (round 4; the tiles are bound by VALU issue at 100 M particles):
+//  * x and y travel as one 64-bit register pair (f32x2): the subtraction, the squares, the two quotients' refinement
+//    chains, the scalings and the final additions are the same operation on both components, and gfx950 issues
+//    v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 -- IEEE binary32 per component, the same rounding as the scalar
+//    forms -- in the slot of one scalar instruction.  Left to itself hipcc packed a quarter of them.
+//  * the predicates are LANE MASKS (vote_* below): every comparison is voted on its own and the masks are combined
+//    by scalar ANDs.  A vote on `a && b` costs two VALU instructions (hipcc materialises the combined predicate as
+//    0 / 1 and compares it again); the response votes three times per pair.
+// `active`: the lanes that have a pair; `plain`: the lanes whose r1 is an ordinary number (1e-30 .. 1e30).  Returns the
+// lanes that collided; (p1, p2) are updated in place for them.
 #ifdef GPE_COUNT_PAIRS
 // diagnostic builds only (scripts/soak_pairs.py): pairs the colour passes walk / resolve, over all tiles (the halo cells a
 // tile recomputes for its neighbours included) -- what "ms per 10^9 pairs" in BASELINE.md is measured with
-__device__ unsigned long long g_pairs_walked, g_pairs_hit;
-__device__ __forceinline__ void count_pairs(unsigned long long *ctr, const bool on)
+// (4096 counters each, by workgroup, 64 bytes apart: two counters for the whole device took 300 ms per step at 100 M; and
+// only while g_pairs_on is set, so that a run reaches the step of interest at nearly the product's speed)
+constexpr int kPairCounters = 4096;
+__device__ unsigned long long g_pairs_walked[kPairCounters * 8], g_pairs_hit[kPairCounters * 8];
+__device__ uint32_t g_pairs_on;
+__device__ __forceinline__ void count_pairs(unsigned long long *ctr, const uint64_t m)
 {
-    const uint64_t m = __ballot(on);
-    if (m != 0 && lane_id() == (int)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__popcll(m));
+    if (m != 0 && g_pairs_on != 0u && lane_id() == (int)__builtin_ctzll(m))
+        atomicAdd(&ctr[(blockIdx.x & (kPairCounters - 1)) * 8], (unsigned long long)__popcll(m));
 }
 #endif
-__device__ __forceinline__ bool pair_response(const bool active, float &p1x, float &p1y, float &p2x, float &p2y,
-                                              const float r1, const float r2, const bool r1_plain,
-                                              const float stiffness, bool &hit)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(const float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 fma2(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 select2(const bool c, const f32x2 a, const f32x2 b) { return (f32x2){c ? a.x : b.x, c ? a.y : b.y}; }
+__device__ __forceinline__ uint64_t plain_radius_lanes(const float r) { return ballot64(r >= 1e-30f) & ballot64(r <= 1e30f); }
+
+// BOTH = false: only p1 is updated (the lane groups, where each lane of a pair computes its own half).
+template <bool BOTH = true>
+__device__ __forceinline__ uint64_t pair_response(const uint64_t active, f32x2 &p1, std::conditional_t<BOTH, f32x2 &, const f32x2 &> p2,
+                                                  const float r1, const float r2, const uint64_t plain,
+                                                  const float stiffness, const uint64_t counted = ~0ull)
 {
+    (void)counted;                                                    // (diagnostic builds: the lanes whose pair counts)
 #ifdef GPE_COUNT_PAIRS
-    count_pairs(&g_pairs_walked, active);
+    count_pairs(g_pairs_walked, active & counted);
 #endif
-    const float vx = p1x - p2x, vy = p1y - p2y;                       // :91 (live positions, :86)
-    const float q = vx * vx + vy * vy;
+    const f32x2 v = p1 - p2;                                          // :91 (live positions, :86)
+    const f32x2 vv = v * v;
+    const float q = vv.x + vv.y;
     const float radius_sum = r1 + r2;                                 // :61
     const float rs2 = radius_sum * radius_sum;
-    const bool cand = active && q <= rs2 * 1.000001f && q >= 9.9e-9f;
-    hit = false;
-    if (__ballot(cand) == 0) return false;                            // wave-uniform
-#ifndef GPE_VAR_LEANMATH
-#define GPE_VAR_LEANMATH 1
-#endif
-#if GPE_VAR_LEANMATH
+    const uint64_t cand = active & ballot64(q <= rs2 * 1.000001f) & ballot64(q >= 9.9e-9f);
+    if (cand == 0) return 0;                                          // wave-uniform
     // The correctly rounded square root and quotients WITHOUT the steps hipcc's sequences spend on operands that
     // cannot occur here: a candidate has q in [9.9e-9, 1.000001 rs^2] and the quotients' numerators are differences
     // of positions (0 or >= one ulp of a position), so nothing is denormal, zero-divided, infinite or NaN; the lanes
@@ -864,56 +882,34 @@ __device__ __forceinline__ bool pair_response(const bool active, float &p1x, flo
         sres = r_up > 0.0f ? s_up : sres;
         distance = sres;                                              // :93
     }
-    hit = cand && rs2 > distance * distance && distance > 0.0001f;    // :95
+    const uint64_t hit = cand & ballot64(rs2 > distance * distance) & ballot64(distance > 0.0001f);   // :95
     const float depth = radius_sum - distance;                        // :97
-    float ux, uy;
+    f32x2 u;
     {
         const float r0 = __builtin_amdgcn_rcpf(distance);
         const float e0 = __builtin_fmaf(-distance, r0, 1.0f);
-        const float r1q = __builtin_fmaf(e0, r0, r0);
-        const float qx0 = vx * r1q, qy0 = vy * r1q;
-        const float qx1 = __builtin_fmaf(__builtin_fmaf(-distance, qx0, vx), r1q, qx0);
-        const float qy1 = __builtin_fmaf(__builtin_fmaf(-distance, qy0, vy), r1q, qy0);
-        ux = __builtin_fmaf(__builtin_fmaf(-distance, qx1, vx), r1q, qx1);
-        uy = __builtin_fmaf(__builtin_fmaf(-distance, qy1, vy), r1q, qy1);
+        const f32x2 rq = splat2(__builtin_fmaf(e0, r0, r0)), nd = splat2(-distance);
+        const f32x2 q0 = v * rq;
+        const f32x2 q1 = fma2(fma2(nd, q0, v), rq, q0);
+        u = fma2(fma2(nd, q1, v), rq, q1);
     }
-    const float cx = (ux * depth) * stiffness;                        // :98,101
-    const float cy = (uy * depth) * stiffness;
-#else
-    const float distance = sqrtf(q);                                  // :93
-    hit = cand && rs2 > distance * distance && distance > 0.0001f;    // :95
-    const float depth = radius_sum - distance;                        // :97
-    const float cx = ((vx / distance) * depth) * stiffness;           // :98,101
-    const float cy = ((vy / distance) * depth) * stiffness;
-#endif
+    const f32x2 c = (u * splat2(depth)) * splat2(stiffness);          // :98,101
     float w1 = 0.5f, w2 = 0.5f;                                       // == inv1 / (inv1 + inv1), exactly
-    const bool general = hit && !(r1 == r2 && r1_plain);
-    if (__ballot(general) != 0) {                                     // wave-uniform: unequal radii somewhere
-        if (general) {
+    const uint64_t general = hit & ~(ballot64(r1 == r2) & plain);     // unequal (or odd) radii somewhere
+    if (general != 0) {                                               // wave-uniform
+        if (lanes_of(general)) {
             const float inv1 = 1.0f / r1, inv2 = 1.0f / r2;           // :103,104
             w1 = inv1 / (inv1 + inv2);                                // :107
             w2 = inv2 / (inv1 + inv2);                                // :108
         }
     }
-    const float n1x = p1x + cx * w1, n1y = p1y + cy * w1;             // :110
-    const float n2x = p2x - cx * w2, n2y = p2y - cy * w2;             // :111
-    p1x = hit ? n1x : p1x; p1y = hit ? n1y : p1y;
-    p2x = hit ? n2x : p2x; p2y = hit ? n2y : p2y;
+    const bool mine = lanes_of(hit);
+    p1 = select2(mine, p1 + c * splat2(w1), p1);                      // :110
+    if constexpr (BOTH) p2 = select2(mine, p2 - c * splat2(w2), p2);  // :111
 #ifdef GPE_COUNT_PAIRS
-    count_pairs(&g_pairs_hit, hit);
+    count_pairs(g_pairs_hit, hit & counted);
 #endif
-    return __ballot(hit) != 0;
-}
-
-// The test pair_response starts with, on its own: can this pair collide at these positions?  (hit implies cand.)
-__device__ __forceinline__ bool pair_candidate(const float ax, const float ay, const float ar, const float bx,
-                                               const float by, const float br)
-{
-    const float vx = ax - bx, vy = ay - by;
-    const float q = vx * vx + vy * vy;
-    const float radius_sum = ar + br;
-    const float rs2 = radius_sum * radius_sum;
-    return q <= rs2 * 1.000001f && q >= 9.9e-9f;
+    return hit;
 }
 
 // The reference's pair resolution (collision_solver.wgsl:66-118), on LDS-resident positions: one lane walks the
@@ -921,28 +917,31 @@ __device__ __forceinline__ bool pair_candidate(const float ax, const float ay, c
 //  * the next partner's position is fetched while the current pair is computed: within one `a` loop every pair
 //    touches a different partner, so that position cannot change in between;
 //  * see pair_response for the arithmetic.
+// (Called under divergent control flow -- the lanes walk cells of different sizes: the votes cover the lanes that are
+// in the same iteration.)
 template <class L>
 __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint32_t e, const float stiffness)
 {
     for (uint32_t ia = b; ia + 1 < e; ++ia) {                         // :68
         const uint32_t a = S.mem[ia];
         uint32_t nb = S.mem[ia + 1];
-        float p1x = S.px[a], p1y = S.py[a];
+        f32x2 p1 = {S.px[a], S.py[a]};
         const float r1 = S.rad[a];
-        float nx = S.px[nb], ny = S.py[nb], nr = S.rad[nb];
-        const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
+        f32x2 nxt = {S.px[nb], S.py[nb]};
+        float nr = S.rad[nb];
+        const uint64_t plain = plain_radius_lanes(r1);
         bool dirty = false;
         for (uint32_t ib = ia + 1; ib < e; ++ib) {                    // :77
             const uint32_t bb = nb;
-            float p2x = nx, p2y = ny;                                 // :86 live position
+            f32x2 p2 = nxt;                                           // :86 live position
             const float r2 = nr;
-            if (ib + 1 < e) { nb = S.mem[ib + 1]; nx = S.px[nb]; ny = S.py[nb]; nr = S.rad[nb]; }
-            bool hit;
-            if (pair_response(true, p1x, p1y, p2x, p2y, r1, r2, r1_plain, stiffness, hit)) {
-                if (hit) { S.px[bb] = p2x; S.py[bb] = p2y; dirty = true; }
+            if (ib + 1 < e) { nb = S.mem[ib + 1]; nxt = (f32x2){S.px[nb], S.py[nb]}; nr = S.rad[nb]; }
+            const uint64_t hit = pair_response(ballot64(true), p1, p2, r1, r2, plain, stiffness);
+            if (hit != 0) {
+                if (lanes_of(hit)) { S.px[bb] = p2.x; S.py[bb] = p2.y; dirty = true; }
             }
         }
-        if (dirty) { S.px[a] = p1x; S.py[a] = p1y; }
+        if (dirty) { S.px[a] = p1.x; S.py[a] = p1.y; }
     }
 }
 
@@ -953,49 +952,49 @@ __device__ __forceinline__ void resolve_cell(L &S, const uint32_t b, const uint3
 // (0,1), (0,2), (1,2) back to back with pair_response's wave-uniform early-outs, the moved positions stored at the
 // end.  The general loop (resolve_cell) walked the same pairs through two nested loops with an LDS round trip per
 // partner: ~60 wave instructions and five dependent round trips more per pass.
-#ifndef GPE_VAR_SMALLCELLS
-#define GPE_VAR_SMALLCELLS 1
-#endif
-
-
+// `on`, `n <= 3` ... must reach this function as comparisons (they are voted on one by one, see pair_response).
 template <class L>
 __device__ __forceinline__ void resolve_small_cells(L &S, const bool on, const uint32_t b, const uint32_t n,
                                                     const float stiffness)
 {
-    const bool small = on && n <= 3u;
-    const bool three = small && n == 3u;
+    const uint64_t on_m = ballot64(on);
+    const uint64_t small_m = on_m & ballot64(n <= 3u), three_m = on_m & ballot64(n == 3u);
+    const bool small = lanes_of(small_m), three = lanes_of(three_m);
     uint32_t m0 = 0, m1 = 0, m2 = 0;
     if (small) { m0 = S.mem[b]; m1 = S.mem[b + 1]; m2 = three ? (uint32_t)S.mem[b + 2] : m1; }
     uint32_t i0 = 0, i1 = 1, i2 = 2;
-    float x0 = 0.f, y0 = 0.f, r0 = 1.f, x1 = 3.f, y1 = 3.f, r1 = 1.f, x2 = 6.f, y2 = 6.f, r2 = 1.f;
-    const bool any3 = __ballot(three) != 0;                            // wave-uniform
+    f32x2 p0 = {0.f, 0.f}, p1 = {3.f, 3.f}, p2 = {6.f, 6.f};
+    float r0 = 1.f, r1 = 1.f, r2 = 1.f;
+    const bool any3 = three_m != 0;                                    // wave-uniform
     if (small) {
-        x0 = S.px[m0]; y0 = S.py[m0]; r0 = S.rad[m0];
-        x1 = S.px[m1]; y1 = S.py[m1]; r1 = S.rad[m1];
+        p0 = (f32x2){S.px[m0], S.py[m0]}; r0 = S.rad[m0];
+        p1 = (f32x2){S.px[m1], S.py[m1]}; r1 = S.rad[m1];
     }
     if (any3) {
-        if (three) { i0 = S.id[m0]; i1 = S.id[m1]; i2 = S.id[m2]; x2 = S.px[m2]; y2 = S.py[m2]; r2 = S.rad[m2]; }
+        if (three) { i0 = S.id[m0]; i1 = S.id[m1]; i2 = S.id[m2]; p2 = (f32x2){S.px[m2], S.py[m2]}; r2 = S.rad[m2]; }
 #define GPE_CSWAP(A, B)                                                                                       \
         {                                                                                                     \
-            const bool sw = three && i##A > i##B;                                                             \
+            const bool sw = lanes_of(three_m & ballot64(i##A > i##B));                                        \
             const uint32_t ta = sw ? i##B : i##A, tb = sw ? i##A : i##B, ma = sw ? m##B : m##A, mb = sw ? m##A : m##B; \
-            const float xa = sw ? x##B : x##A, xb = sw ? x##A : x##B, ya = sw ? y##B : y##A, yb = sw ? y##A : y##B;    \
+            const f32x2 pa = select2(sw, p##B, p##A), pb = select2(sw, p##A, p##B);                           \
             const float ra = sw ? r##B : r##A, rb = sw ? r##A : r##B;                                         \
-            i##A = ta; i##B = tb; m##A = ma; m##B = mb; x##A = xa; x##B = xb; y##A = ya; y##B = yb; r##A = ra; r##B = rb; \
+            i##A = ta; i##B = tb; m##A = ma; m##B = mb; p##A = pa; p##B = pb; r##A = ra; r##B = rb;           \
         }
         GPE_CSWAP(0, 1) GPE_CSWAP(1, 2) GPE_CSWAP(0, 1)
 #undef GPE_CSWAP
     }
-    const bool plain0 = r0 >= 1e-30f && r0 <= 1e30f, plain1 = r1 >= 1e-30f && r1 <= 1e30f;
-    bool h01 = false, h02 = false, h12 = false;
-    (void)pair_response(small, x0, y0, x1, y1, r0, r1, plain0, stiffness, h01);
+    const uint64_t plain0 = plain_radius_lanes(r0);
+    uint64_t h01 = 0, h02 = 0, h12 = 0;
+    h01 = pair_response(small_m, p0, p1, r0, r1, plain0, stiffness);
     if (any3) {
-        (void)pair_response(three, x0, y0, x2, y2, r0, r2, plain0, stiffness, h02);
-        (void)pair_response(three, x1, y1, x2, y2, r1, r2, plain1, stiffness, h12);
+        h02 = pair_response(three_m, p0, p2, r0, r2, plain0, stiffness);
+        h12 = pair_response(three_m, p1, p2, r1, r2, plain_radius_lanes(r1), stiffness);
     }
-    if (h01 | h02) { S.px[m0] = x0; S.py[m0] = y0; }
-    if (h01 | h12) { S.px[m1] = x1; S.py[m1] = y1; }
-    if (h02 | h12) { S.px[m2] = x2; S.py[m2] = y2; }
+    if ((h01 | h02 | h12) != 0) {                                      // wave-uniform
+        if (lanes_of(h01 | h02)) { S.px[m0] = p0.x; S.py[m0] = p0.y; }
+        if (lanes_of(h01 | h12)) { S.px[m1] = p1.x; S.py[m1] = p1.y; }
+        if (lanes_of(h02 | h12)) { S.px[m2] = p2.x; S.py[m2] = p2.y; }
+    }
     if (on && n > 3u) {                                                // a pile in the one-lane list: the general walk
         sort_members(S, b, b + n);
         resolve_cell(S, b, b + n, stiffness);
@@ -1004,77 +1003,99 @@ __device__ __forceinline__ void resolve_small_cells(L &S, const bool on, const u
 
 // A cell of 4..8 members resolved by kGroupLanes consecutive lanes of one wave.  The reference's pair sequence
 // (a, b), a < b in ascending object index (:68-118) only orders pairs that share a particle; pair (a, b) can
-// run as soon as (a, b-1) and (a-1, b) are done, i.e. at step a + b - 1 of a wavefront schedule -- 2n - 3 steps
-// instead of n (n-1) / 2, every particle still seeing its updates in the reference's order.
-// The lanes form a systolic array: lane a owns particle a (registers); particle b enters at lane 0 at step
-// b - 1, meets one owner per step -- pair (a, b) at lane a -- and moves one lane up through a DPP row shift
-// until it reaches lane b, where it becomes that lane's own particle one step before its first pair (b, b+1).
-// Lane 0 is fed by a second pipe running down the lanes.  No LDS access inside the loop; same arithmetic per
-// pair as resolve_cell, so the same bits.  A colour pass
-// lasts as long as its slowest cell: this is what shortens it.
+// run as soon as (a, b-1) and (a-1, b) are done, i.e. at step s = a + b of a wavefront schedule (s = 1 .. 2n - 3)
+// -- 2n - 3 steps instead of n (n-1) / 2, every particle still seeing its updates in the reference's order.
+// Lane a of the group owns particle a (registers) for the whole walk.  At step s its partner is particle s - a: the
+// two lanes of a pair each fetch the other's live position and radius through two DPP moves -- the reflection
+// i <-> s - i of an 8-lane group is row_half_mirror (i <-> 7 - i) followed by a row shift by |7 - s|, both fixed at
+// compile time because the steps are unrolled -- and EACH COMPUTES ITS OWN HALF of the response as "particle 1".
+// That is exact: seen from the other side v is negated, and negation commutes with every operation of the chain
+// (squares and the distance are the same; products, the fused refinement steps and the final addition are odd in v;
+// r1 + r2 and inv1 + inv2 commute), so lane b's p_b + (-c) w_b is the reference's p_b - c w_b bit for bit -- the
+// symmetry the two-member cells already rely on.  (Rounds 1-3 moved the visitors through the lanes instead: a pipe up,
+// a feed pipe down and their bookkeeping -- seven DPP moves and as many selects per step, and both halves of every
+// response in one lane.  The steps mostly stop at the candidate test, so their fixed cost is what a group costs.)
+// No LDS access inside the walk.  A colour pass lasts as long as its slowest cell: this is what shortens it.
 constexpr uint32_t kGroupLanes = 8, kGroupMin = 4;
-__device__ __forceinline__ float dpp_from_lane_below(float v)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(const float v)
 {
-    // row_shr:1 -- lane i of a 16-lane row reads lane i - 1 (lane 0 of the row reads 0)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+    // (bound_ctrl: a source lane outside the row, or switched off, reads as 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ int dpp_from_lane_below(int v)
+constexpr int kDppHalfMirror = 0x141;
+// the value lane (S - i) of the 8-lane group holds, given the group's half-mirrored values (lane i holds lane 7 - i's)
+template <int S>
+__device__ __forceinline__ float dpp_reflect_from_mirrored(const float m)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    if constexpr (S < 7) return dpp_mov<0x100 + (7 - S)>(m);          // row_shl: lane i reads lane i + (7 - S)
+    else if constexpr (S > 7) return dpp_mov<0x110 + (S - 7)>(m);     // row_shr: lane i reads lane i - (S - 7)
+    else return m;
 }
-__device__ __forceinline__ float dpp_from_lane_above(float v)
+// lanes whose partner at step S can exist at all: 0 <= S - a, S - a != a  (a = lane mod 8)
+template <int S, bool LOWER = false>
+constexpr uint64_t group_step_lanes()
 {
-    // row_shl:1 -- lane i of a 16-lane row reads lane i + 1 (the last lane of the row reads 0)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true));
+    uint64_t m = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int a = lane & 7;
+        if (a <= S && 2 * a != S && (!LOWER || 2 * a < S)) m |= 1ull << lane;
+    }
+    return m;
 }
-template <class L>
+template <int S, int SMAX, class F>
+__device__ __forceinline__ void for_each_group_step(F &&f)
+{
+    f(std::integral_constant<int, S>{});
+    if constexpr (S < SMAX) for_each_group_step<S + 1, SMAX>(f);
+}
+// NMAX: the most members a group cell of this window form can have
+template <int NMAX, class L>
 __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint32_t n, const int a,
                                               const float stiffness)
 {
+    static_assert(NMAX >= (int)kGroupMin && NMAX <= (int)kGroupLanes, "group cells: 4 .. 8 members");
     const int group_base = lane_id() & ~((int)kGroupLanes - 1);
     // order the members: rank = members with a smaller object index (they are distinct)
-    const bool has = (uint32_t)a < n;
+    const uint64_t has_m = ballot64((uint32_t)a < n);
+    const bool has = lanes_of(has_m);
     const uint32_t my_slot = has ? (uint32_t)S.mem[b + a] : 0u;
     const uint32_t my_id = has ? S.id[my_slot] : 0xFFFFFFFFu;
     uint32_t rank = 0;
 #pragma unroll
-    for (int i = 0; i < (int)kGroupLanes; ++i) rank += ((uint32_t)__shfl((int)my_id, i, kGroupLanes) < my_id) ? 1u : 0u;
+    for (int i = 0; i < NMAX; ++i) rank += ((uint32_t)__shfl((int)my_id, i, kGroupLanes) < my_id) ? 1u : 0u;
     // forward permute: lane r receives the slot of the member of rank r
     const uint32_t a_slot = (uint32_t)__builtin_amdgcn_ds_permute((group_base + (int)(has ? rank : (uint32_t)a)) << 2,
                                                                   (int)my_slot);
-    // step-start state of the lane's particle; also what lane 0 is fed with (nothing touches particle b before
-    // its first pair (0, b))
-    float ox = 0.f, oy = 0.f, r1 = 1.f;
-    if (has) { ox = S.px[a_slot]; oy = S.py[a_slot]; r1 = S.rad[a_slot]; }
-    float p1x = ox, p1y = oy;
-    const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
-    float qx = 0.f, qy = 0.f, qr = 1.f;                               // the particle this lane passes on
-    int qb = -1;                                                      // ... its index in the cell, -1: none
-    const int last = 2 * (int)n - 3;
-    // the feed: a second pipe running DOWN the lanes, one lane per step, primed so that lane 0 finds particle
-    // t + 1 in it at step t (what arrives from beyond the cell's lanes is never used: ib < n)
-    float fx = dpp_from_lane_above(ox), fy = dpp_from_lane_above(oy), fr = dpp_from_lane_above(r1);
-    for (int t = 0; t <= last; ++t) {
-        float ix = dpp_from_lane_below(qx), iy = dpp_from_lane_below(qy), ir = dpp_from_lane_below(qr);
-        int ib = dpp_from_lane_below(qb);
-        if (a == 0) { ix = fx; iy = fy; ir = fr; ib = (t + 1 < (int)n) ? t + 1 : -1; }
-        fx = dpp_from_lane_above(fx); fy = dpp_from_lane_above(fy); fr = dpp_from_lane_above(fr);
-        qb = -1;
-        if (ib == a) {                                                // the lane's own particle has arrived
-            p1x = ix; p1y = iy;
+    f32x2 o = {0.f, 0.f};                                             // step-start state of the lane's particle
+    float r1 = 1.f;
+    if (has) { o = (f32x2){S.px[a_slot], S.py[a_slot]}; r1 = S.rad[a_slot]; }
+    f32x2 p1 = o;
+    const uint64_t plain = plain_radius_lanes(r1);
+    const float r_mirrored = dpp_mov<kDppHalfMirror>(r1);
+    const uint32_t n_plus_a = n + (uint32_t)a;                        // partner s - a exists while s - a < n
+    // how long the longest schedule of the wave is (the cells of a wave differ): steps beyond 2 * 4 - 3 are skipped
+    // by a scalar test unless some cell has the members for them
+    const uint64_t any5 = has_m & ballot64(n >= 5u), any6 = has_m & ballot64(n >= 6u), any7 = has_m & ballot64(n >= 7u),
+                   any8 = has_m & ballot64(n >= 8u);
+    for_each_group_step<1, 2 * NMAX - 3>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int need = (s + 4) / 2;                              // smallest n with 2n - 3 >= s
+        if constexpr (need >= 5) {
+            const uint64_t any = need == 5 ? any5 : (need == 6 ? any6 : (need == 7 ? any7 : any8));
+            if (any == 0) return;                                      // wave-uniform
         }
-        // pair (a, ib), step t == a + ib - 1: every lane runs the straight-line response, lanes without a pair
-        // this step are masked out by `active`
-        const bool pairing = ib > a && has;
-        bool hit;
-        (void)pair_response(pairing, p1x, p1y, ix, iy, r1, ir, r1_plain, stiffness, hit);
-        if (pairing) {
-            qx = ix; qy = iy; qr = ir; qb = ib;
-        }
-    }
-    if (has && (__float_as_uint(p1x) != __float_as_uint(ox) || __float_as_uint(p1y) != __float_as_uint(oy))) {
-        S.px[a_slot] = p1x;
-        S.py[a_slot] = p1y;
+        const f32x2 ip = {dpp_reflect_from_mirrored<s>(dpp_mov<kDppHalfMirror>(p1.x)),
+                          dpp_reflect_from_mirrored<s>(dpp_mov<kDppHalfMirror>(p1.y))};
+        const float ir = dpp_reflect_from_mirrored<s>(r_mirrored);
+        constexpr uint64_t kStepLanes = group_step_lanes<s>();
+        const uint64_t pairing = has_m & kStepLanes & ballot64((uint32_t)s < n_plus_a);
+        constexpr uint64_t kLower = group_step_lanes<s, true>();      // (the lane with the smaller index of each pair)
+        (void)pair_response<false>(pairing, p1, ip, r1, ir, plain, stiffness, kLower);
+    });
+    if (has && (__float_as_uint(p1.x) != __float_as_uint(o.x) || __float_as_uint(p1.y) != __float_as_uint(o.y))) {
+        S.px[a_slot] = p1.x;
+        S.py[a_slot] = p1.y;
     }
 }
 
@@ -1094,40 +1115,47 @@ __device__ __forceinline__ float wave_from_lane_above(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
 }
+__device__ __forceinline__ f32x2 wave_from_lane_below(f32x2 v) { return (f32x2){wave_from_lane_below(v.x), wave_from_lane_below(v.y)}; }
+__device__ __forceinline__ f32x2 wave_from_lane_above(f32x2 v) { return (f32x2){wave_from_lane_above(v.x), wave_from_lane_above(v.y)}; }
 template <class L>
 __device__ __forceinline__ void resolve_wave(L &S, const uint32_t b, const uint32_t n, const float stiffness)
 {
     const int a = lane_id();
-    const bool has = (uint32_t)a < n;
+    const uint64_t has_m = ballot64((uint32_t)a < n);
+    const bool has = lanes_of(has_m);
     const uint32_t my_slot = has ? (uint32_t)S.mem[b + a] : 0u;
     const uint32_t my_id = has ? S.id[my_slot] : 0xFFFFFFFFu;
     uint32_t rank = 0;
     for (int i = 0; i < (int)n; ++i)                                    // n is wave-uniform: v_readlane
         rank += ((uint32_t)__builtin_amdgcn_readlane((int)my_id, i) < my_id) ? 1u : 0u;
     const uint32_t a_slot = (uint32_t)__builtin_amdgcn_ds_permute((int)(has ? rank : (uint32_t)a) << 2, (int)my_slot);
-    float ox = 0.f, oy = 0.f, r1 = 1.f;
-    if (has) { ox = S.px[a_slot]; oy = S.py[a_slot]; r1 = S.rad[a_slot]; }
-    float p1x = ox, p1y = oy;
-    const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
-    float qx = 0.f, qy = 0.f, qr = 1.f;
+    f32x2 o = {0.f, 0.f};
+    float r1 = 1.f;
+    if (has) { o = (f32x2){S.px[a_slot], S.py[a_slot]}; r1 = S.rad[a_slot]; }
+    f32x2 p1 = o;
+    const uint64_t plain = plain_radius_lanes(r1);
+    f32x2 qp = {0.f, 0.f};
+    float qr = 1.f;
     int qb = -1;
     const int last = 2 * (int)n - 3;
-    float fx = wave_from_lane_above(ox), fy = wave_from_lane_above(oy), fr = wave_from_lane_above(r1);
+    const bool first = a == 0;
+    f32x2 fp = wave_from_lane_above(o);
+    float fr = wave_from_lane_above(r1);
     for (int t = 0; t <= last; ++t) {
-        float ix = wave_from_lane_below(qx), iy = wave_from_lane_below(qy), ir = wave_from_lane_below(qr);
+        f32x2 ip = wave_from_lane_below(qp);
+        float ir = wave_from_lane_below(qr);
         int ib = wave_from_lane_below(qb);
-        if (a == 0) { ix = fx; iy = fy; ir = fr; ib = (t + 1 < (int)n) ? t + 1 : -1; }
-        fx = wave_from_lane_above(fx); fy = wave_from_lane_above(fy); fr = wave_from_lane_above(fr);
-        qb = -1;
-        if (ib == a) { p1x = ix; p1y = iy; }                           // the lane's own particle has arrived
-        const bool pairing = ib > a && has;
-        bool hit;
-        (void)pair_response(pairing, p1x, p1y, ix, iy, r1, ir, r1_plain, stiffness, hit);
-        if (pairing) { qx = ix; qy = iy; qr = ir; qb = ib; }
+        if (first) { ip = fp; ir = fr; ib = (t + 1 < (int)n) ? t + 1 : -1; }
+        fp = wave_from_lane_above(fp); fr = wave_from_lane_above(fr);
+        if (ib == a) p1 = ip;                                          // the lane's own particle has arrived
+        const uint64_t pairing_m = has_m & ballot64(ib > a);
+        (void)pair_response(pairing_m, p1, ip, r1, ir, plain, stiffness);
+        // (what a lane without a pair passes on is marked "none" and never looked at)
+        qp = ip; qr = ir; qb = lanes_of(pairing_m) ? ib : -1;
     }
-    if (has && (__float_as_uint(p1x) != __float_as_uint(ox) || __float_as_uint(p1y) != __float_as_uint(oy))) {
-        S.px[a_slot] = p1x;
-        S.py[a_slot] = p1y;
+    if (has && (__float_as_uint(p1.x) != __float_as_uint(o.x) || __float_as_uint(p1.y) != __float_as_uint(o.y))) {
+        S.px[a_slot] = p1.x;
+        S.py[a_slot] = p1.y;
     }
 }
 
@@ -1181,47 +1209,48 @@ __device__ __forceinline__ void resolve_wave_blocked(L &S, const uint32_t b, con
         if (I + 1 == chunks) break;
         wave_lds_order();
         // the owners of this block row
-        const bool has = (uint32_t)a < cI;
+        const uint64_t has_m = ballot64((uint32_t)a < cI);
+        const bool has = lanes_of(has_m);
         const uint32_t o_slot = has ? (uint32_t)S.mem[bI + a] : 0u;
-        float p1x = 0.f, p1y = 0.f, r1 = 1.f;
-        if (has) { p1x = S.px[o_slot]; p1y = S.py[o_slot]; r1 = S.rad[o_slot]; }
-        const float ox = p1x, oy = p1y;
-        const bool r1_plain = r1 >= 1e-30f && r1 <= 1e30f;
+        f32x2 p1 = {0.f, 0.f};
+        float r1 = 1.f;
+        if (has) { p1 = (f32x2){S.px[o_slot], S.py[o_slot]}; r1 = S.rad[o_slot]; }
+        const f32x2 o = p1;
+        const uint64_t plain = plain_radius_lanes(r1);
+        const bool first = a == 0;
         for (uint32_t J = I + 1; J < chunks; ++J) {
             const uint32_t bJ = b + 64u * J, cJ = min(64u, n - 64u * J);
-            float qx = 0.f, qy = 0.f, qr = 1.f;
+            f32x2 qp = {0.f, 0.f};
+            float qr = 1.f;
             int qb = -1, qs = 0;
             // lane 0 fetches the visitor one step ahead
-            float nx = 0.f, ny = 0.f, nr = 1.f;
+            f32x2 np = {0.f, 0.f};
+            float nr = 1.f;
             int ns = 0;
-            if (a == 0) { ns = (int)S.mem[bJ]; nx = S.px[ns]; ny = S.py[ns]; nr = S.rad[ns]; }
+            if (first) { ns = (int)S.mem[bJ]; np = (f32x2){S.px[ns], S.py[ns]}; nr = S.rad[ns]; }
             const int steps = (int)(cI + cJ) - 1;
             for (int t = 0; t < steps; ++t) {
-                float ix = wave_from_lane_below(qx), iy = wave_from_lane_below(qy), ir = wave_from_lane_below(qr);
+                f32x2 ip = wave_from_lane_below(qp);
+                float ir = wave_from_lane_below(qr);
                 int ib = wave_from_lane_below(qb), is = wave_from_lane_below(qs);
-                if (a == 0) {
-                    ix = nx; iy = ny; ir = nr; is = ns;
+                if (first) {
+                    ip = np; ir = nr; is = ns;
                     ib = t < (int)cJ ? t : -1;
-                    if (t + 1 < (int)cJ) { ns = (int)S.mem[bJ + t + 1]; nx = S.px[ns]; ny = S.py[ns]; nr = S.rad[ns]; }
+                    if (t + 1 < (int)cJ) { ns = (int)S.mem[bJ + t + 1]; np = (f32x2){S.px[ns], S.py[ns]}; nr = S.rad[ns]; }
                 }
-                const bool pairing = has && ib >= 0;
-                const float bx0 = ix, by0 = iy;
-                bool hit;
-                (void)pair_response(pairing, p1x, p1y, ix, iy, r1, ir, r1_plain, stiffness, hit);
-                // the visitor leaves the block behind the last owner: store it if it moved on its way
-                if (pairing && (uint32_t)a + 1u == cI) {
-                    // (it may have been moved by lower lanes: compare with what lane 0 read is not possible here,
-                    // so store whenever this block touched it; an unchanged store is harmless)
-                    S.px[is] = ix; S.py[is] = iy;
-                }
-                (void)bx0; (void)by0;
-                qx = ix; qy = iy; qr = ir; qb = pairing ? ib : -1; qs = is;
+                const uint64_t pairing_m = has_m & ballot64(ib >= 0);
+                (void)pair_response(pairing_m, p1, ip, r1, ir, plain, stiffness);
+                const bool pairing = lanes_of(pairing_m);
+                // the visitor leaves the block behind the last owner: store it (it may have been moved by lower
+                // lanes; an unchanged store is harmless)
+                if (pairing && (uint32_t)a + 1u == cI) { S.px[is] = ip.x; S.py[is] = ip.y; }
+                qp = ip; qr = ir; qb = pairing ? ib : -1; qs = is;
             }
             wave_lds_order();
         }
-        if (has && (__float_as_uint(p1x) != __float_as_uint(ox) || __float_as_uint(p1y) != __float_as_uint(oy))) {
-            S.px[o_slot] = p1x;
-            S.py[o_slot] = p1y;
+        if (has && (__float_as_uint(p1.x) != __float_as_uint(o.x) || __float_as_uint(p1.y) != __float_as_uint(o.y))) {
+            S.px[o_slot] = p1.x;
+            S.py[o_slot] = p1.y;
         }
         wave_lds_order();
     }
@@ -1440,7 +1469,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             uint64_t mq[QP];
             uint32_t cnt = 0;
 #pragma unroll
-            for (int q = 0; q < QP; ++q) { mq[q] = __ballot(keep[q]); cnt += (uint32_t)__popcll(mq[q]); }
+            for (int q = 0; q < QP; ++q) { mq[q] = ballot64(keep[q]); cnt += (uint32_t)__popcll(mq[q]); }
             uint32_t base = 0;
             if (lane == 0 && cnt) base = atomicAdd(&S.misc[3], cnt);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1498,7 +1527,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         bool keep = have && lx >= 0 && lx < RWX && ly >= 0 && ly < RWY;
         uint32_t sl = P + (uint32_t)tid;                               // the spill window: slots behind the looked-up ones
         if constexpr (kTrim) {
-            const uint64_t mk = __ballot(keep);
+            const uint64_t mk = ballot64(keep);
             uint32_t base = 0;
             if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1541,7 +1570,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
             bool keep = have && lx < RWX && ly < RWY;
             uint32_t sl = P + n_exc + gi;                               // the spill window: behind the stragglers
             if constexpr (kTrim) {
-                const uint64_t mk = __ballot(keep);
+                const uint64_t mk = ballot64(keep);
                 uint32_t base = 0;
                 if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1710,8 +1739,8 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                     if (k < (uint32_t)WC) S.wlist[c * WC + k] = (uint16_t)lc[c]; else wavec = false;
                 }
                 single[c] = act && !group[c] && !wavec;
-                mg[c] = __ballot(group[c]);
-                ms[c] = __ballot(single[c]);
+                mg[c] = ballot64(group[c]);
+                ms[c] = ballot64(single[c]);
             }
             // the eight list counters (colour x class) are bumped by eight lanes at once: one LDS round trip for
             // the wave instead of eight dependent ones
@@ -1765,7 +1794,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #ifdef GPE_DBG_SKIP
                 if (!(GPE_DBG_SKIP & 8))
 #endif
-                resolve_group(S, b, e - b, (int)(i % kGroupLanes), A.stiffness);
+                resolve_group<(int)kGroupLanes>(S, b, e - b, (int)(i % kGroupLanes), A.stiffness);
             } else if (i >= single_base && (i & ~63u) < work) {         // (whole waves: the walk uses ballots)
                 const bool on = i < work;
                 uint32_t b = 0, e = 0;
@@ -2255,11 +2284,12 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * NT;
             lxq[q] = code_window_x(cc[q], ox);
             lyq[q] = code_window_y(cc[q], oy);
-            keep[q] = s < P && lxq[q] < RWX && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
+            // (voted comparison by comparison: see pair_response)
+            mq[q] = ballot64(s < P) & ballot64(lxq[q] < RWX) & ballot64(lyq[q] < RWY) & ballot64((cc[q] & straggler_bit) == 0u);
             // (an order-key window: the kept table -- or the roster written from it -- may still list indices the owned
             // range has shrunk below: those particles are ghosts now, or gone; they come through the ghost list, or not at all)
-            if constexpr (ORD) keep[q] = keep[q] && lidq[q] < n_owned;
-            mq[q] = __ballot(keep[q]);
+            if constexpr (ORD) mq[q] &= ballot64(lidq[q] < n_owned);
+            keep[q] = lanes_of(mq[q]);
             cnt += (uint32_t)__popcll(mq[q]);
         }
         uint32_t base = 0;
@@ -2285,8 +2315,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         const uint32_t lidq = pid;
         if constexpr (ORD) pid = A.order_keys[pid];
         const int lx = (int)(en.y & 0xFFFFu) - ox, ly = (int)(en.y >> 16) - oy;
-        bool keep = have && lx >= 0 && lx < RWX && ly >= 0 && ly < RWY;
-        const uint64_t mk = __ballot(keep);
+        const uint64_t mk = ballot64(have) & ballot64((uint32_t)lx < (uint32_t)RWX) & ballot64((uint32_t)ly < (uint32_t)RWY);
+        bool keep = lanes_of(mk);
         uint32_t base = 0;
         if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -2305,8 +2335,8 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             const uint32_t cc = A.codes[lidq];
             const uint32_t pid = A.order_keys[lidq];
             const int lx = code_window_x(cc, ox), ly = code_window_y(cc, oy);
-            bool keep = have && lx < RWX && ly < RWY;
-            const uint64_t mk = __ballot(keep);
+            const uint64_t mk = ballot64(have) & ballot64(lx < RWX) & ballot64(ly < RWY);
+            bool keep = lanes_of(mk);
             uint32_t base = 0;
             if (lane == 0 && mk) base = atomicAdd(&S.misc[3], (uint32_t)__popcll(mk));
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -2375,27 +2405,32 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                 zc[0] = z0; zc[1] = z0 + 1; zc[2] = z0 + ZX; zc[3] = z0 + ZX + 1;
                 cnt[0] = w0 & 0xFFFFu; cnt[1] = w0 >> 16; cnt[2] = w1 & 0xFFFFu; cnt[3] = w1 >> 16;
             }
+            // (the classes as lane masks, voted comparison by comparison: see pair_response)
             uint64_t ms[4], mg[4];
             bool single[4], group[4];
+            const uint64_t in_m = ballot64(i < QC);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int lx = gx2 + (c & 1) + L::ZOX, ly = gy2 + (c >> 1) + L::ZOY;   // window coordinates
                 const int gxx = ox + lx, gyy = oy + ly;
                 const int exl = HX - lx, exr = lx - (HX + TX - 1), eyl = HY - ly, eyr = ly - (HY + TY - 1);
-                const bool in_zone = exl <= kConeLeft - c && exr <= kConeRight - c && eyl <= kConeDown - (c >> 1) &&
-                                     eyr <= kConeUp - (c >> 1);
-                const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
-                const bool act = (cnt[c] >= 2) && !unused_alias && in_zone;
-                group[c] = act && cnt[c] >= kGroupMin && cnt[c] <= (uint32_t)MS;
-                bool wavec = act && cnt[c] > (uint32_t)MS;
-                if (wavec) {
-                    if (cnt[c] > 64u) S.misc[2] = 1u;                  // a pile: the sub-tile windows resolve those
-                    const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
-                    if (k < (uint32_t)L::WC) S.wlist[c * L::WC + k] = (uint16_t)zc[c]; else S.misc[2] = 1u;
+                const uint64_t zone_m = ballot64(exl <= kConeLeft - c) & ballot64(exr <= kConeRight - c) &
+                                        ballot64(eyl <= kConeDown - (c >> 1)) & ballot64(eyr <= kConeUp - (c >> 1));
+                // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell (collision_cell_builder.wgsl:56)
+                const uint64_t alias_m = ballot64((gxx & 0xFFFF) == 0xFFFF) & ballot64((gyy & 0xFFFF) == 0xFFFF);
+                const uint64_t act_m = in_m & ballot64(cnt[c] >= 2u) & zone_m & ~alias_m;
+                const uint64_t wave_m = act_m & ballot64(cnt[c] > (uint32_t)MS);
+                mg[c] = act_m & ballot64(cnt[c] >= kGroupMin) & ~wave_m;
+                ms[c] = act_m & ~mg[c] & ~wave_m;
+                group[c] = lanes_of(mg[c]);
+                single[c] = lanes_of(ms[c]);
+                if (wave_m != 0) {                                     // (scalar: rare)
+                    if (lanes_of(wave_m)) {
+                        if (cnt[c] > 64u) S.misc[2] = 1u;              // a pile: the sub-tile windows resolve those
+                        const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
+                        if (k < (uint32_t)L::WC) S.wlist[c * L::WC + k] = (uint16_t)zc[c]; else S.misc[2] = 1u;
+                    }
                 }
-                single[c] = act && !group[c] && !wavec;
-                mg[c] = __ballot(group[c]);
-                ms[c] = __ballot(single[c]);
             }
             uint32_t mine = 0;
 #pragma unroll
@@ -2434,7 +2469,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #endif
             if (i < group_lanes) {
                 const uint32_t en = S.list[k * QZ + (QZ - 1) - (i / kGroupLanes)];
-                resolve_group(S, (en & 0xFFFu) * MS, (en >> 12) + kGroupMin, (int)(i % kGroupLanes), A.stiffness);
+                resolve_group<MS>(S, (en & 0xFFFu) * MS, (en >> 12) + kGroupMin, (int)(i % kGroupLanes), A.stiffness);
             } else if (i >= single_base && (i & ~63u) < work) {         // (whole waves: the walk uses ballots)
                 const bool on = i < work;
                 uint32_t b = 0, n = 0;
@@ -2457,7 +2492,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                 const uint32_t e = e0 + (uint32_t)lane;
                 const uint32_t v = e < n_big ? S.big[e] : 0xFFFFFFFFu;
                 const bool hit = e < n_big && (v >> 16) == zc;
-                const uint64_t mh = __ballot(hit);
+                const uint64_t mh = ballot64(hit);
                 if (hit) S.mem[wb + filled + popc_below_lane(mh)] = (uint16_t)(v & 0xFFFFu);
                 filled += (uint32_t)__popcll(mh);
             }
@@ -3248,7 +3283,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_shard_classify(const float2 *_
             // bits 26-30: 1 + owner of that block when it is not this rank (the particle migrates)
             info = (dest_mask_of_block[b] & 0x03FFFFFFu) | ((owner != my_rank) ? ((owner + 1u) << 26) : 0u);
         }
-        const uint64_t m = __ballot(info != 0);
+        const uint64_t m = ballot64(info != 0);
         if (m == 0) continue;
         const int leader = (int)__builtin_ctzll(m);
         uint32_t base = 0;
@@ -3280,16 +3315,20 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
 // diagnostic builds only: (pairs walked, pairs resolved) since the last reset
 extern "C" gpe_status gpe_debug_pair_counts(gpe_ctx *c, uint64_t *out2, int32_t reset)
 {
+    // out2 = (pairs walked, pairs resolved) since the last reset; reset != 0 also switches the counting on, reset < 0 off
     if (!c || !out2) return GPE_ERR_INVALID_ARG;
     (void)hipStreamSynchronize(c->stream);
-    unsigned long long w = 0, h = 0;
-    (void)hipMemcpyFromSymbol(&w, HIP_SYMBOL(gpe::g_pairs_walked), sizeof(w));
-    (void)hipMemcpyFromSymbol(&h, HIP_SYMBOL(gpe::g_pairs_hit), sizeof(h));
-    out2[0] = w; out2[1] = h;
+    static unsigned long long w[gpe::kPairCounters * 8], h[gpe::kPairCounters * 8];
+    (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(gpe::g_pairs_walked), sizeof(w));
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(gpe::g_pairs_hit), sizeof(h));
+    out2[0] = out2[1] = 0;
+    for (int i = 0; i < gpe::kPairCounters; ++i) { out2[0] += w[i * 8]; out2[1] += h[i * 8]; }
     if (reset) {
-        w = 0;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_pairs_walked), &w, sizeof(w));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_pairs_hit), &w, sizeof(w));
+        memset(w, 0, sizeof(w));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_pairs_walked), w, sizeof(w));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_pairs_hit), w, sizeof(w));
+        const uint32_t on = reset > 0 ? 1u : 0u;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_pairs_on), &on, sizeof(on));
     }
     return GPE_OK;
 }

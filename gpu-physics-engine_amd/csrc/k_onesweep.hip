@@ -255,14 +255,14 @@ __global__ __launch_bounds__(kOsBlock, GPE_OS_MINWAVES) void k_os_pass(const uin
             // Clustered digits (keys of neighbouring particles: a wave holds a handful of values) are peeled off
             // with ballots, one value per step -- many lanes ORing into ONE LDS word serialise; what is left
             // after kPeel values (scattered digits) meets through the LDS match table.
-            u64 rem = __ballot(valid);
+            u64 rem = ballot64(valid);
             u64 mine = 0ull;
 #pragma unroll
             for (int it = 0; it < kPeel; ++it) {
                 if (rem == 0) break;                                   // wave-uniform
                 const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rem));
                 const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
-                const u64 same = __ballot(valid && d == d0) & rem;
+                const u64 same = ballot64(valid && d == d0) & rem;
                 if (d == d0) mine = same;
                 rem &= ~same;
             }

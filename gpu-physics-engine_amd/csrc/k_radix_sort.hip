@@ -22,11 +22,11 @@ constexpr int kWaveSpan = 64 * kSortItems;            // contiguous keys owned b
 // Lanes holding the same 8-bit digit (among `valid` lanes).  8 ballots, one per digit bit.
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
 {
-    uint64_t m = __ballot(valid);
+    uint64_t m = ballot64(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
+        const uint64_t bal = ballot64(bit);
         m &= bit ? bal : ~bal;
     }
     return m;

@@ -12,6 +12,9 @@ __global__ __launch_bounds__(64) void probe(float *out, unsigned long long *cyc,
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3, i4 = i0 + 4, i5 = i0 + 5, i6 = i0 + 6, i7 = i0 + 7;
     const float m = 1.0000001f, c = 1e-9f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v0 = {a0, a1}, v1 = {a2, a3}, v2 = {a4, a5}, v3 = {a6, a7}, v4 = {a1, a0}, v5 = {a3, a2}, v6 = {a5, a4}, v7 = {a7, a6};
+    const f2 m2 = {m, m}, c2 = {c, c};
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -25,6 +28,17 @@ __global__ __launch_bounds__(64) void probe(float *out, unsigned long long *cyc,
             } else if (KIND == 2) {   // compare + select
                 a0 = a0 > a1 ? a2 : a0; a1 = a1 > a2 ? a3 : a1; a2 = a2 > a3 ? a4 : a2; a3 = a3 > a4 ? a5 : a3;
                 a4 = a4 > a5 ? a6 : a4; a5 = a5 > a6 ? a7 : a5; a6 = a6 > a7 ? a0 : a6; a7 = a7 > a0 ? a1 : a7;
+            } else if (KIND == 4) {   // independent packed FMAs (v_pk_fma_f32: two f32 per lane)
+                v0 = __builtin_elementwise_fma(v0, m2, c2); v1 = __builtin_elementwise_fma(v1, m2, c2); v2 = __builtin_elementwise_fma(v2, m2, c2); v3 = __builtin_elementwise_fma(v3, m2, c2);
+                v4 = __builtin_elementwise_fma(v4, m2, c2); v5 = __builtin_elementwise_fma(v5, m2, c2); v6 = __builtin_elementwise_fma(v6, m2, c2); v7 = __builtin_elementwise_fma(v7, m2, c2);
+            } else if (KIND == 5) {   // independent packed multiplies then adds (v_pk_mul_f32, v_pk_add_f32; 16 instructions)
+                v0 = v0 * m2; v1 = v1 * m2; v2 = v2 * m2; v3 = v3 * m2; v4 = v4 * m2; v5 = v5 * m2; v6 = v6 * m2; v7 = v7 * m2;
+                asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+                v0 = v0 + c2; v1 = v1 + c2; v2 = v2 + c2; v3 = v3 + c2; v4 = v4 + c2; v5 = v5 + c2; v6 = v6 + c2; v7 = v7 + c2;
+                asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+            } else if (KIND == 6) {   // one dependent chain of packed FMAs (latency)
+                v0 = __builtin_elementwise_fma(v0, m2, c2); v0 = __builtin_elementwise_fma(v0, m2, c2); v0 = __builtin_elementwise_fma(v0, m2, c2); v0 = __builtin_elementwise_fma(v0, m2, c2);
+                v0 = __builtin_elementwise_fma(v0, m2, c2); v0 = __builtin_elementwise_fma(v0, m2, c2); v0 = __builtin_elementwise_fma(v0, m2, c2); v0 = __builtin_elementwise_fma(v0, m2, c2);
             } else {                  // one dependent chain (latency)
                 a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c);
                 a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c);
@@ -32,6 +46,7 @@ __global__ __launch_bounds__(64) void probe(float *out, unsigned long long *cyc,
         }
     }
     const long long t1 = clock64();
+    a0 += v0.x + v0.y + v1.x + v1.y + v2.x + v2.y + v3.x + v3.y + v4.x + v4.y + v5.x + v5.y + v6.x + v6.y + v7.x + v7.y;
     out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7);
     if (threadIdx.x == 0) cyc[blockIdx.x] = (unsigned long long)(t1 - t0);
 }
@@ -67,5 +82,8 @@ int main()
     for (int w : {1, 2, 4, 8}) run<1>("iadd+xor", w, 16);
     for (int w : {1, 2, 4, 8}) run<2>("cmp+sel", w, 16);
     for (int w : {1, 2, 4, 8}) run<3>("dep-fma", w, 8);
+    for (int w : {1, 2, 4, 8}) run<4>("pk_fma", w, 8);
+    for (int w : {1, 2, 4, 8}) run<5>("pk_mul+add", w, 16);
+    for (int w : {1, 2, 4, 8}) run<6>("dep-pk_fma", w, 8);
     return 0;
 }

@@ -26,7 +26,7 @@ for m in marks:
     t0 = time.perf_counter(); advance(window); st.ctx.sync(); el = time.perf_counter() - t0
     msg = "n=%d around step %5d: %8.3f ms/step  sorts %3d of %d" % (n, m, el / window * 1e3, st.ctx.pipeline_info()["native_sorts"] - s0, window)
     if counter:
-        counter(st.ctx.h, out, 0)
+        counter(st.ctx.h, out, -1)
         msg += "  pairs walked %.4g / step, resolved %.4g / step (diagnostic build: the time is not the product's)" % (out[0] / window, out[1] / window)
     print(msg, flush=True)
 print(st.ctx.pipeline_info())
