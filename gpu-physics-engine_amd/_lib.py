@@ -49,7 +49,9 @@ class GpeConfig(C.Structure):
 class GpePipelineInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("pipeline", C.c_uint32), ("reason", C.c_uint32),
                 ("sort_passes", C.c_uint32), ("native_steps", C.c_uint64), ("compat_steps", C.c_uint64),
-                ("native_sorts", C.c_uint64), ("window_max", C.c_uint32), ("roster_stamp", C.c_uint32)]
+                ("native_sorts", C.c_uint64), ("window_max", C.c_uint32), ("roster_stamp", C.c_uint32),
+                ("overflow_tiles", C.c_uint32), ("overflow_subtiles", C.c_uint32), ("overflow_spills", C.c_uint32),
+                ("arena_slots", C.c_uint32)]
 
 
 class GpeTiming(C.Structure):

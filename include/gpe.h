@@ -172,6 +172,12 @@ typedef struct gpe_pipeline_info {
     uint32_t window_max;         /* largest 24x24-cell window population last reported by the tiles                */
     uint32_t roster_stamp;       /* the sort count the tile rosters are checked against (the tiles' own copy of    */
                                  /* native_sorts, low 32 bits: the two are equal or the rosters would be stale)    */
+    /* what the tiles of the last reported NATIVE step did (lagged by the steps in flight; a host that fills in a   */
+    /* struct_size up to roster_stamp gets the fields above only):                                                   */
+    uint32_t overflow_tiles;     /* 32x32 tiles handed to the over-capacity launch                                  */
+    uint32_t overflow_subtiles;  /* 16x16 quarters of those redone as four 8x8 tiles                                */
+    uint32_t overflow_spills;    /* 8x8 tiles staged in the global spill arena                                      */
+    uint32_t arena_slots;        /* spill-arena slots handed out                                                    */
 } gpe_pipeline_info;
 gpe_status gpe_get_pipeline_info(gpe_ctx *ctx, gpe_pipeline_info *info);
 

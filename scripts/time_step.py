@@ -20,6 +20,6 @@ st.ctx.sync()
 tim = st.ctx.timings()
 tag = " ".join("%s=%s" % (k, os.environ[k]) for k in sorted(os.environ) if k.startswith("GPE_"))
 pi = st.ctx.pipeline_info()
-tag += " flags=%d sorts %d of %d steps" % (flags, pi["native_sorts"], pi["native_steps"])
+tag += " flags=%d sorts %d of %d steps, over-capacity tiles %d" % (flags, pi["native_sorts"], pi["native_steps"], pi["overflow_tiles"])
 print("n=%d %s  wall %.4f ms/step | " % (n, tag, wall) +
       "  ".join("%s %.1fus" % (k, v[0] / max(1, v[1]) * 1e3) for k, v in sorted(tim.items(), key=lambda kv: -kv[1][0])), flush=True)

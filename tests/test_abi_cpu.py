@@ -46,7 +46,7 @@ def test_config_defaults_are_the_reference_constants(gpe):
     assert gpe._lib.load().gpe_compute_cell_size(10.0) == 22.0               # tests/grid.rs:109
     # the fast pipeline is the default (it falls back to the COMPAT kernels by itself); no switches set
     assert cfg.mode == gpe._lib.MODE_NATIVE and cfg.flags == 0
-    assert ctypes.sizeof(gpe._lib.GpeConfig) == 64 and ctypes.sizeof(gpe._lib.GpePipelineInfo) == 48
+    assert ctypes.sizeof(gpe._lib.GpeConfig) == 64 and ctypes.sizeof(gpe._lib.GpePipelineInfo) == 64
 
 
 def test_no_gpu_means_loud_failure_not_fallback(gpe):
