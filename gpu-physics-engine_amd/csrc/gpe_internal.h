@@ -106,6 +106,13 @@ __device__ __forceinline__ uint64_t ballot64(const bool p) { return __builtin_am
 // `a && b && c` where the combined predicate is also voted on (pair_response, k_native.hip).
 __device__ __forceinline__ bool lanes_of(const uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// lane LANE of `v` = the wave-uniform `value`: one v_writelane_b32
+template <int LANE>
+__device__ __forceinline__ void write_lane(int &v, const int value)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(LANE));
+}
+
 // number of set bits of `m` strictly below this lane
 __device__ __forceinline__ uint32_t popc_below_lane(uint64_t m)
 {

@@ -966,22 +966,26 @@ __device__ __forceinline__ void resolve_small_cells(L &S, const bool on, const u
     f32x2 p0 = {0.f, 0.f}, p1 = {3.f, 3.f}, p2 = {6.f, 6.f};
     float r0 = 1.f, r1 = 1.f, r2 = 1.f;
     const bool any3 = three_m != 0;                                    // wave-uniform
+    // The three-element network on (object index, slot) only; positions and radii are loaded by the ordered slots
+    // afterwards: 10 selects instead of the 28 that ordered positions and radii as well, for one more LDS round trip in a
+    // wave that holds a cell of three (round 4: -27 VALU lane-slots per particle, -1.5 % at every size).
+    if (any3) {
+        if (three) { i0 = S.id[m0]; i1 = S.id[m1]; i2 = S.id[m2]; }
+#define GPE_CSWAP(A, B)                                                                                       \
+        {                                                                                                     \
+            const bool sw = lanes_of(three_m & ballot64(i##A > i##B));                                        \
+            const uint32_t ta = sw ? i##B : i##A, tb = sw ? i##A : i##B, ma = sw ? m##B : m##A, mb = sw ? m##A : m##B; \
+            i##A = ta; i##B = tb; m##A = ma; m##B = mb;                                                       \
+        }
+        GPE_CSWAP(0, 1) GPE_CSWAP(1, 2) GPE_CSWAP(0, 1)
+#undef GPE_CSWAP
+    }
     if (small) {
         p0 = (f32x2){S.px[m0], S.py[m0]}; r0 = S.rad[m0];
         p1 = (f32x2){S.px[m1], S.py[m1]}; r1 = S.rad[m1];
     }
     if (any3) {
-        if (three) { i0 = S.id[m0]; i1 = S.id[m1]; i2 = S.id[m2]; p2 = (f32x2){S.px[m2], S.py[m2]}; r2 = S.rad[m2]; }
-#define GPE_CSWAP(A, B)                                                                                       \
-        {                                                                                                     \
-            const bool sw = lanes_of(three_m & ballot64(i##A > i##B));                                        \
-            const uint32_t ta = sw ? i##B : i##A, tb = sw ? i##A : i##B, ma = sw ? m##B : m##A, mb = sw ? m##A : m##B; \
-            const f32x2 pa = select2(sw, p##B, p##A), pb = select2(sw, p##A, p##B);                           \
-            const float ra = sw ? r##B : r##A, rb = sw ? r##A : r##B;                                         \
-            i##A = ta; i##B = tb; m##A = ma; m##B = mb; p##A = pa; p##B = pb; r##A = ra; r##B = rb;           \
-        }
-        GPE_CSWAP(0, 1) GPE_CSWAP(1, 2) GPE_CSWAP(0, 1)
-#undef GPE_CSWAP
+        if (three) { p2 = (f32x2){S.px[m2], S.py[m2]}; r2 = S.rad[m2]; }
     }
     const uint64_t plain0 = plain_radius_lanes(r0);
     uint64_t h01 = 0, h02 = 0, h12 = 0;
@@ -1806,11 +1810,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 if (!(GPE_DBG_SKIP & 16))
 #endif
                 {
-#if GPE_VAR_SMALLCELLS
                     resolve_small_cells(S, on, b, e - b, A.stiffness);
-#else
-                    if (on) { sort_members(S, b, e); resolve_cell(S, b, e, A.stiffness); }
-#endif
                 }
             }
         }
@@ -2416,8 +2416,11 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                 const int exl = HX - lx, exr = lx - (HX + TX - 1), eyl = HY - ly, eyr = ly - (HY + TY - 1);
                 const uint64_t zone_m = ballot64(exl <= kConeLeft - c) & ballot64(exr <= kConeRight - c) &
                                         ballot64(eyl <= kConeDown - (c >> 1)) & ballot64(eyr <= kConeUp - (c >> 1));
-                // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell (collision_cell_builder.wgsl:56)
-                const uint64_t alias_m = ballot64((gxx & 0xFFFF) == 0xFFFF) & ballot64((gyy & 0xFFFF) == 0xFFFF);
+                // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell (collision_cell_builder.wgsl:56).
+                // Cell (-1, -1) lies in the zone of tile (0, 0) alone (the box has at most 65000 cells per axis, so no
+                // other coordinate ends in 0xFFFF): a scalar test spares every other tile the comparisons.
+                uint64_t alias_m = 0;
+                if (tx == 0 && ty == 0) alias_m = ballot64((gxx & 0xFFFF) == 0xFFFF) & ballot64((gyy & 0xFFFF) == 0xFFFF);
                 const uint64_t act_m = in_m & ballot64(cnt[c] >= 2u) & zone_m & ~alias_m;
                 const uint64_t wave_m = act_m & ballot64(cnt[c] > (uint32_t)MS);
                 mg[c] = act_m & ballot64(cnt[c] >= kGroupMin) & ~wave_m;
@@ -2432,14 +2435,15 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                     }
                 }
             }
-            uint32_t mine = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                mine = (lane == c) ? (uint32_t)__popcll(ms[c]) : mine;
-                mine = (lane == 4 + c) ? (uint32_t)__popcll(mg[c]) : mine;
-            }
+            // the eight list counters (colour x class) are bumped by eight lanes at once: the counts are scalars, each
+            // written into its lane by one v_writelane
+            int mine = 0;
+            write_lane<0>(mine, (int)__popcll(ms[0])); write_lane<1>(mine, (int)__popcll(ms[1]));
+            write_lane<2>(mine, (int)__popcll(ms[2])); write_lane<3>(mine, (int)__popcll(ms[3]));
+            write_lane<4>(mine, (int)__popcll(mg[0])); write_lane<5>(mine, (int)__popcll(mg[1]));
+            write_lane<6>(mine, (int)__popcll(mg[2])); write_lane<7>(mine, (int)__popcll(mg[3]));
             uint32_t mybase = 0;
-            if (lane < 8 && mine) mybase = atomicAdd(&S.lcnt[lane], mine);
+            if (lane < 8 && mine) mybase = atomicAdd(&S.lcnt[lane], (uint32_t)mine);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)mybase, c);

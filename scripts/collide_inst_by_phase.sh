@@ -6,7 +6,7 @@
 set -u
 N=${1:-16000000}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03/inst_by_phase
+OUT=$ROOT/gpurun_out/r04/inst_by_phase
 mkdir -p "$OUT"
 L=$ROOT/gpu-physics-engine_amd/libgpe.so
 cp $L /tmp/libgpe_default.so
