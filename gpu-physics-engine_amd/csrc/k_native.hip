@@ -148,8 +148,23 @@ constexpr uint64_t kArenaMaxSlots = 1ull << 30; // the arena's slot numbers are 
 constexpr int kTileMain = 32, kCapMain = GPE_CAP_MAIN;
 // The sub-tile windows take the same LDS as the main one, so the launch for over-capacity tiles also runs four
 // workgroups per CU (with 1920 / 2048-particle windows it ran two: half the waves to hide latency with).
-constexpr int kTileMid = 16, kCapMid = 1200;
-constexpr int kTileSmall = 8, kCapSmall = 1200;
+// (Round 4: 1600-particle sub-tile windows, three workgroups per CU at 80 VGPRs, looked-up capacity 8 x 512 -- against
+// 1200 / four per CU / 64 VGPRs / 6 x 512: -1.4 % at step 1250 and -7.5 % at step 2000 of the 100 M soak; 2000-particle
+// windows at two per CU and 128 VGPRs, which spill nothing: +5 % / -7 %.  profiles/r04/soak_marks_overflow_windows.txt)
+#ifndef GPE_CAP_MID
+#define GPE_CAP_MID 1600
+#endif
+#ifndef GPE_CAP_SMALL
+#define GPE_CAP_SMALL 1600
+#endif
+#ifndef GPE_QMAX_MID
+#define GPE_QMAX_MID 8
+#endif
+#ifndef GPE_OVF_WAVES
+#define GPE_OVF_WAVES 6                        // waves per SIMD the over-capacity launch is compiled for (512 VGPRs / this)
+#endif
+constexpr int kTileMid = 16, kCapMid = GPE_CAP_MID;
+constexpr int kTileSmall = 8, kCapSmall = GPE_CAP_SMALL;
 // sharded (order-key) instantiations: 4 more bytes per slot for the local index, so 1024 slots in the same LDS
 #ifndef GPE_CAP_ORD
 #define GPE_CAP_ORD 1024
@@ -576,6 +591,7 @@ struct CollideArgs {
     float stiffness;
     int32_t gx, gy;              // cell box
     int32_t tiles_x, tiles_y;    // tile grid of the dense launch
+    uint32_t band_rows;          // ... dealt to the XCDs in bands of this many tile rows (dense_launch_tile)
     int32_t tile_x0, tile_y0;    // its first tile (sharded runs cut the grid to the rank's active box)
     const uint32_t *order_keys;  // sharded runs: in-cell order by order_keys[local index]; else NULL
     uint32_t *tile_ctl;          // kCtl* words
@@ -619,6 +635,21 @@ __device__ __forceinline__ void pack_if_near_border(const PackArgs &P, const boo
 }
 constexpr int kRosterCap = GPE_QMAX_MAIN_VALUE * 512;   // == TileDirect<32, .., 512>::RAWCAP
 
+#ifdef GPE_TILE_CYCLES
+// diagnostic builds only (scripts/tile_cycles.py): what every tile of the dense launch and every quarter of the
+// over-capacity launch cost -- g_tile_cycles[tile of the tile box] = (cycles of the dense launch's workgroup, outcome:
+// 0 done / 1 handed on, cycles of its quarters in the over-capacity launch, particles it looked up)
+__device__ uint4 *g_tile_cycles;
+#endif
+#ifdef GPE_DBG_RT
+// diagnostic builds only (scripts/overflow_phases.py): parts of the counting-sort windows' colour passes switched off at
+// run time (1 lane groups, 2 one-lane cells, 4 whole-wave cells, 8 everything behind P1) -- what a part costs in a scene
+// that only exists after a thousand steps of the product's kernels.  Results are wrong while a bit is set.
+__device__ uint32_t g_dbg_skip_rt;
+#define GPE_RT_SKIP(bit) ((g_dbg_skip_rt & (bit)) != 0u)
+#else
+#define GPE_RT_SKIP(bit) false
+#endif
 #ifdef GPE_TILE_STAMPS
 #define GPE_STAMP_BEGIN() long long _t_prev = clock64()
 #define GPE_STAMP(i)                                                                  \
@@ -667,7 +698,7 @@ struct TileLds {
 #ifndef GPE_QMAX_MAIN
 #define GPE_QMAX_MAIN GPE_QMAX_MAIN_VALUE
 #endif
-    static constexpr int QMAX = T >= 32 ? GPE_QMAX_MAIN : (T >= 16 ? 6 : 8);
+    static constexpr int QMAX = T >= 32 ? GPE_QMAX_MAIN : (T >= 16 ? GPE_QMAX_MID : 8);
     static constexpr int RAWCAP = QMAX * kNatThreads;
     static_assert(NCELL < 2048, "hm packs home (11 bit) | overlap mask (8) | own (1)");
     static constexpr int QZ = (T + 8) * (T + 4) / 4;                      // cells of one colour inside its zone
@@ -1457,23 +1488,27 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
         int lxq[QP], lyq[QP];
         bool keep[QP];
         uint32_t slot[QP];
+        uint64_t mq[QP];
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const uint32_t s = s0 + (uint32_t)tid + (uint32_t)q * kNatThreads;
             lxq[q] = code_window_x(cc[q], ox);
             lyq[q] = code_window_y(cc[q], oy);
-            keep[q] = s < P && lxq[q] < RWX && lyq[q] < RWY && (cc[q] & straggler_bit) == 0u;
+            // (voted comparison by comparison, the masks combined by scalar ANDs: see pair_response)
+            mq[q] = ballot64(s < P) & ballot64(lxq[q] < RWX) & ballot64(lyq[q] < RWY) & ballot64((cc[q] & straggler_bit) == 0u);
             // (an order-key window: the kept table may still list indices the owned range has shrunk below -- those
             // particles are ghosts now, or gone: they come through the ghosts' table, or not at all)
-            if constexpr (ORD) keep[q] = keep[q] && (A.gtable == nullptr || blk[q] >= (uint32_t)NBLK || lidq[q] < n_owned_now);
+            if constexpr (ORD) {
+                if (A.gtable != nullptr) mq[q] &= ballot64(blk[q] >= (uint32_t)NBLK) | ballot64(lidq[q] < n_owned_now);
+            }
+            keep[q] = lanes_of(mq[q]);
             slot[q] = s;
         }
         if constexpr (kTrim) {
             // kept particles get consecutive slots: one LDS atomic per wave (the order of the slots is free)
-            uint64_t mq[QP];
             uint32_t cnt = 0;
 #pragma unroll
-            for (int q = 0; q < QP; ++q) { mq[q] = ballot64(keep[q]); cnt += (uint32_t)__popcll(mq[q]); }
+            for (int q = 0; q < QP; ++q) cnt += (uint32_t)__popcll(mq[q]);
             uint32_t base = 0;
             if (lane == 0 && cnt) base = atomicAdd(&S.misc[3], cnt);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1713,9 +1748,11 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 cnt[c] = 0;
                 if (i < QC) cnt[c] = S.cell_get(lc[c] + 1) - S.cell_get(lc[c]);
             }
+            // (the classes as lane masks, voted comparison by comparison: see pair_response)
             uint64_t ms[4], mg[4];
             bool single[4], group[4];
             constexpr int WC = L::WC;
+            const uint64_t in_m = ballot64(i < QC);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int lx = hx + (c & 1), ly = hy + (c >> 1);
@@ -1723,28 +1760,33 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 // cells beyond the tile's edges on each side; the colour's zone (kCone*): colour c + 1 reaches
                 // 4 - c cells left, 3 - c right, 2 - (c >> 1) down, 1 - (c >> 1) up
                 const int exl = HX - lx, exr = lx - (HX + T - 1), eyl = HY - ly, eyr = ly - (HY + T - 1);
-                const bool in_zone = exl <= kConeLeft - c && exr <= kConeRight - c && eyl <= kConeDown - (c >> 1) &&
-                                     eyr <= kConeUp - (c >> 1);
+                const uint64_t zone_m = ballot64(exl <= kConeLeft - c) & ballot64(exr <= kConeRight - c) &
+                                        ballot64(eyl <= kConeDown - (c >> 1)) & ballot64(eyr <= kConeUp - (c >> 1));
                 // morton(-1,-1) == 0xFFFFFFFF == UNUSED_CELL_ID: never a collision cell
                 // (collision_cell_builder.wgsl:56); cells outside the colour's exactness zone are skipped
-                const bool unused_alias = ((gxx & 0xFFFF) == 0xFFFF) && ((gyy & 0xFFFF) == 0xFFFF);
-                const bool act = (cnt[c] >= 2) && !unused_alias && in_zone;
+                const uint64_t alias_m = ballot64((gxx & 0xFFFF) == 0xFFFF) & ballot64((gyy & 0xFFFF) == 0xFFFF);
+                const uint64_t act_m = in_m & ballot64(cnt[c] >= 2u) & zone_m & ~alias_m;
                 // cells of 4..8 members go to the BACK of the colour's segment: they are resolved by a group
                 // of 8 lanes (resolve_group); the others fill the segment from the front (one lane each)
-                group[c] = act && (cnt[c] >= kGroupMin) && (cnt[c] <= kGroupLanes);
+                mg[c] = act_m & ballot64(cnt[c] >= kGroupMin) & ballot64(cnt[c] <= kGroupLanes);
                 // cells of 9..64 members go to a whole wave each (resolve_wave), as far as the colour's list takes
                 // (65..256 members: blocked, in the sub-tile and spill windows only; a main tile that meets such a
                 // cell hands itself over to them)
                 constexpr uint32_t kWaveMax = (T >= 32) ? 64u : kWaveCellMax;
-                if (T >= 32 && act && cnt[c] > 64u) S.misc[2] = 1u;
-                bool wavec = act && cnt[c] > kGroupLanes && cnt[c] <= kWaveMax;
-                if (wavec) {
-                    const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
-                    if (k < (uint32_t)WC) S.wlist[c * WC + k] = (uint16_t)lc[c]; else wavec = false;
+                const uint64_t big_m = act_m & ballot64(cnt[c] > kGroupLanes);
+                uint64_t wave_m = big_m & ballot64(cnt[c] <= kWaveMax);
+                if (big_m != 0) {                                      // (scalar: no such cell in most rounds)
+                    if (T >= 32 && lanes_of(big_m) && cnt[c] > 64u) S.misc[2] = 1u;
+                    bool wavec = lanes_of(wave_m);
+                    if (wavec) {
+                        const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
+                        if (k < (uint32_t)WC) S.wlist[c * WC + k] = (uint16_t)lc[c]; else wavec = false;
+                    }
+                    wave_m = ballot64(wavec);                          // (cells the wave list had no room for: one lane)
                 }
-                single[c] = act && !group[c] && !wavec;
-                mg[c] = ballot64(group[c]);
-                ms[c] = ballot64(single[c]);
+                ms[c] = act_m & ~mg[c] & ~wave_m;
+                group[c] = lanes_of(mg[c]);
+                single[c] = lanes_of(ms[c]);
             }
             // the eight list counters (colour x class) are bumped by eight lanes at once: one LDS round trip for
             // the wave instead of eight dependent ones
@@ -1798,6 +1840,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #ifdef GPE_DBG_SKIP
                 if (!(GPE_DBG_SKIP & 8))
 #endif
+                if (!GPE_RT_SKIP(1u))
                 resolve_group<(int)kGroupLanes>(S, b, e - b, (int)(i % kGroupLanes), A.stiffness);
             } else if (i >= single_base && (i & ~63u) < work) {         // (whole waves: the walk uses ballots)
                 const bool on = i < work;
@@ -1809,12 +1852,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 #ifdef GPE_DBG_SKIP
                 if (!(GPE_DBG_SKIP & 16))
 #endif
-                {
+                if (!GPE_RT_SKIP(2u)) {
                     resolve_small_cells(S, on, b, e - b, A.stiffness);
                 }
             }
         }
         for (uint32_t i = (uint32_t)(tid >> 6); i < nw; i += kNatWaves) {     // wave-uniform
+            if (GPE_RT_SKIP(4u)) break;
             const int lc = S.wlist[k * L::WC + i];
             const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
             if (e - b <= 64u) resolve_wave(S, b, e - b, A.stiffness);
@@ -2549,16 +2593,48 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 // k_collide_overflow.  (64 x 32-cell tiles on 1024 threads -- two per CU, the window 1.32 x the tile's own cells instead of
 // 1.48 x -- were built, are exact and 5-6.5 % slower: profiles/r03/ab_wide_tiles_64x32_1024_threads_rejected.txt, the
 // code in profiles/r04/wide_tiles_64x32_removed.patch.)
+// Which tile does workgroup `wg` of the dense launch take?  Workgroups go round the eight XCDs (wg mod 8), and the tiles an
+// XCD works through should be neighbours -- they share halo particles in that XCD's L2 -- so every XCD walks BANDS of
+// A.band_rows tile rows, band b belonging to XCD b mod 8, from the bottom of the box to its top.  (Rounds 1-3 gave each XCD
+// one contiguous eighth of the rows.  A scene stratified in y -- anything under gravity: a crushed pile at the bottom,
+// free fall above, nothing at the top -- then loads the XCDs so unevenly that the launch took twice the time its work
+// amounts to: 6.4 ms for 3.3 ms of workgroup time at step 1250 of the 100 M soak, profiles/r04/tile_cycles_*.txt.)
+// Returns false when the workgroup has no tile.
+__device__ __forceinline__ bool dense_launch_tile(const CollideArgs &A, const uint32_t wg, int *tx, int *ty)
+{
+    const uint32_t xcd = wg & 7u, j = wg >> 3;
+    const uint32_t band_tiles = A.band_rows * (uint32_t)A.tiles_x;     // tiles of a band
+    const uint32_t band = (j / band_tiles) * 8u + xcd;                 // the j-th tile of this XCD lies in this band
+    const uint32_t t = band * band_tiles + j % band_tiles;
+    if (t >= (uint32_t)A.tiles_x * (uint32_t)A.tiles_y) return false;
+    *tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x);
+    *ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
+    return true;
+}
+// ... and the grid that covers every tile
+static uint32_t dense_launch_grid(uint32_t tiles_x, uint32_t tiles_y, uint32_t band_rows)
+{
+    const uint32_t bands = (tiles_y + band_rows - 1) / band_rows;
+    return ((bands + 7u) / 8u) * band_rows * tiles_x * 8u;
+}
+
 template <int TX, int CAP, bool ORD, int NT>
 __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
 {
     __shared__ TileDirect<TX, 32, CAP, ORD, NT> S;
-    const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
-    const uint32_t per_xcd = (total + 7u) / 8u;
-    const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
-    const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
-    if (!process_tile_direct<ORD>(S, A, tx, ty)) {
+    int tx, ty;
+    if (!dense_launch_tile(A, blockIdx.x, &tx, &ty)) return;
+#ifdef GPE_TILE_CYCLES
+    const long long tc0 = clock64();
+#endif
+    const bool done = process_tile_direct<ORD>(S, A, tx, ty);
+#ifdef GPE_TILE_CYCLES
+    if (g_tile_cycles && threadIdx.x == 0 && A.tb.holds(tx, ty)) {
+        uint4 *e = &g_tile_cycles[A.tb.index(tx, ty)];
+        e->x = (uint32_t)(clock64() - tc0); e->y = done ? 0u : 1u; e->z = 0u; e->w = S.misc[0];
+    }
+#endif
+    if (!done) {
         if (threadIdx.x == 0) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
             if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
@@ -2573,11 +2649,8 @@ template <int T, int CAP, bool ORD>
 __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide_dense(CollideArgs A)
 {
     __shared__ TileLds<T, CAP, ORD> S;
-    const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
-    const uint32_t per_xcd = (total + 7u) / 8u;
-    const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || t >= total) return;
-    const int tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x), ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
+    int tx, ty;
+    if (!dense_launch_tile(A, blockIdx.x, &tx, &ty)) return;
     // A tile whose window exceeds the capacity returns early and is listed for k_collide_overflow.  (Redoing it
     // here, quarter by quarter, on steps whose statistics let the host skip that launch: the extra code costs this
     // kernel 3 % at 1 M and 5 % at 100 M, more than the 4.5 us launch: profiles/r02/ab_inline_fallback_rejected.txt.)
@@ -2596,7 +2669,7 @@ __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide
 // walks live -- and is still faster than with 85 or 128 VGPRs and three or two workgroups per CU: 12.1 against 13.1 /
 // 15.2 ms in the compressed 100 M scene, profiles/r02/soak_1500_overflow_kernel_register_budget.txt.)
 template <bool ORD>
-__global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs A)
+__global__ __launch_bounds__(kNatThreads, GPE_OVF_WAVES) void k_collide_overflow(CollideArgs A)
 {
     __shared__ OverflowLds<ORD> u;
     __shared__ uint32_t s_item;
@@ -2614,7 +2687,14 @@ __global__ __launch_bounds__(kNatThreads, 8) void k_collide_overflow(CollideArgs
         __syncthreads();
         if (i >= work) break;
         const uint32_t parent = A.overflow1[i >> 2];
+#ifdef GPE_TILE_CYCLES
+        const long long tq0 = clock64();
+#endif
         resolve_quarter<ORD>(u, A, (int)((parent & 0xFFFFu) * 2u + (i & 1u)), (int)((parent >> 16) * 2u + ((i >> 1) & 1u)));
+#ifdef GPE_TILE_CYCLES
+        if (g_tile_cycles && threadIdx.x == 0 && A.tb.holds((int)(parent & 0xFFFFu), (int)(parent >> 16)))
+            atomicAdd(&g_tile_cycles[A.tb.index((int)(parent & 0xFFFFu), (int)(parent >> 16))].z, (uint32_t)(clock64() - tq0));
+#endif
     }
 }
 
@@ -3197,7 +3277,27 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
-        const uint32_t grid = ((total + 7u) / 8u) * 8u;
+        // Bands of up to 8 tile rows (at least four bands per XCD where the box has the rows for it), of the height that
+        // leaves the busiest XCD the fewest rows: 298 rows in bands of 8 give five XCDs 40 rows and two 32 -- the launch
+        // then lasts 40 rows, 7 % longer than the 37.25 of an even deal (measured: +4.7 % at 100 M); in bands of 2 the
+        // busiest has 38.
+        {
+            const int most = std::min(8, std::max(1, A.tiles_y / 32));
+            int best_r = 1, best_rows = 1 << 30;
+            for (int r = most; r >= 1; --r) {
+                const int bands = (A.tiles_y + r - 1) / r;
+                int worst = 0;
+                for (int k = 0; k < 8; ++k) {
+                    int rows = 0;
+                    for (int b = k; b < bands; b += 8) rows += std::min(r, A.tiles_y - b * r);
+                    worst = std::max(worst, rows);
+                }
+                if (worst < best_rows) { best_rows = worst; best_r = r; }
+            }
+            A.band_rows = (uint32_t)best_r;
+        }
+        if (c->cfg.flags & GPE_FLAG_XCD_EIGHTHS) A.band_rows = (uint32_t)((A.tiles_y + 7) / 8);   // (rounds 1-3: one band per XCD)
+        const uint32_t grid = dense_launch_grid((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, A.band_rows);
         // Which form of the tile?  The direct-slot form is the faster one while tiles fit it; it holds 928 particles and
         // hands a tile on when its cells crowd (more than 96 memberships beyond a cell's sixth, a cell of more than 64).
         // In a compressed scene (the 100 M cloud after a few hundred steps of gravity) most tiles would take that
@@ -3314,6 +3414,41 @@ gpe_status launch_shard_classify(gpe_ctx *c, const uint8_t *owner_of_block, cons
 }
 
 }  // namespace gpe
+
+#ifdef GPE_TILE_CYCLES
+// diagnostic builds only: start recording (out == NULL: a buffer of one uint4 per tile of the tile box is attached) or
+// download what the last step recorded (out: tiles x 4 words; *tiles_x / *tiles_y the tile box)
+extern "C" gpe_status gpe_debug_tile_cycles(gpe_ctx *c, uint32_t *out, uint64_t words, uint32_t *tiles_x, uint32_t *tiles_y)
+{
+    if (!c) return GPE_ERR_INVALID_ARG;
+    gpe::NativeState &N = c->native;
+    static uint4 *buf = nullptr;
+    static uint64_t cap = 0;
+    (void)hipStreamSynchronize(c->stream);
+    const uint64_t tiles = N.exc_tiles;
+    if (tiles_x) *tiles_x = (uint32_t)N.tb.nx;
+    if (tiles_y) *tiles_y = (uint32_t)N.tb.ny;
+    if (!out) {
+        if (cap < tiles) { if (buf) (void)hipFree(buf); if (hipMalloc((void **)&buf, tiles * sizeof(uint4)) != hipSuccess) return GPE_ERR_HIP; cap = tiles; }
+        (void)hipMemset(buf, 0, tiles * sizeof(uint4));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_tile_cycles), &buf, sizeof(buf));
+        return GPE_OK;
+    }
+    if (!buf || words < tiles * 4) return GPE_ERR_INVALID_ARG;
+    (void)hipMemcpy(out, buf, tiles * sizeof(uint4), hipMemcpyDeviceToHost);
+    return GPE_OK;
+}
+#endif
+
+#ifdef GPE_DBG_RT
+extern "C" gpe_status gpe_debug_skip(gpe_ctx *c, uint32_t mask)
+{
+    if (!c) return GPE_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_dbg_skip_rt), &mask, sizeof(mask));
+    return GPE_OK;
+}
+#endif
 
 #ifdef GPE_COUNT_PAIRS
 // diagnostic builds only: (pairs walked, pairs resolved) since the last reset

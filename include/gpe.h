@@ -78,8 +78,10 @@ enum {
     GPE_FLAG_NATIVE_STATS = 4u,      /* print the tile statistics to stderr every 128 steps                          */
     GPE_FLAG_SAFE_SORT = 8u,         /* per-module sorts by the communication-free reduce-then-scan radix sort       */
                                      /* (k_radix_sort.hip) instead of onesweep: an in-GPU cross-check                */
-    GPE_FLAG_COUNTING_SORT_TILES = 16u /* NATIVE: the dense launch builds its member lists by a counting sort       */
+    GPE_FLAG_COUNTING_SORT_TILES = 16u, /* NATIVE: the dense launch builds its member lists by a counting sort      */
                                      /* (rounds 1-2) instead of direct cell slots; for A/B timing                    */
+    GPE_FLAG_XCD_EIGHTHS = 64u       /* NATIVE: every XCD works through one contiguous eighth of the tile rows       */
+                                     /* (rounds 1-3) instead of interleaved bands of rows; for A/B timing            */
 };
 
 /* Fills *cfg with the reference's compile-time constants. */

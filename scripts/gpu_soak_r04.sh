@@ -23,8 +23,8 @@ fi
 [[ " $LEGS " == *" trace "* ]] || exit 0
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/soak_trace; mkdir -p $OUT/soak_trace
-timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $OUT/soak_trace -- python3 $ROOT/scripts/soak_pairs.py 100000000 100 1250 2450 > $OUT/soak_trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/soak_trace.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $OUT/soak_trace -- python3 $ROOT/scripts/soak_pairs.py 100000000 100 ${TRACE_MARKS:-1250 2450} > $OUT/soak_trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/soak_trace.log; exit 1; }
 f=$(find $OUT/soak_trace -name '*kernel_trace.csv' | head -1)
-python3 $ROOT/scripts/trace_windows.py $f 10:110 1200:1300 2400:2500 > $OUT/soak_kernels_by_window.txt
+python3 $ROOT/scripts/trace_windows.py $f ${TRACE_WINDOWS:-10:110 1200:1300 2400:2500} > $OUT/soak_kernels_by_window.txt
 rm -rf $OUT/soak_trace
 cat $OUT/soak_kernels_by_window.txt

@@ -8,7 +8,7 @@ gpe = importlib.import_module("gpu-physics-engine_amd")
 n, window, marks = int(sys.argv[1]), int(sys.argv[2]), [int(v) for v in sys.argv[3:]]
 world = gpe.scenes.world_for(n)
 pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
-st = gpe.State(pos, rad, world=world, gravity=(0.0, -9.81), mode=gpe.MODE_NATIVE)
+st = gpe.State(pos, rad, world=world, gravity=(0.0, -9.81), mode=gpe.MODE_NATIVE, flags=int(os.environ.get("SOAK_FLAGS", "0")))
 lib = gpe._lib.load()
 counter = getattr(lib, "gpe_debug_pair_counts", None)
 done = 0
