@@ -22,6 +22,7 @@ FLAG_NATIVE_STATS = 4
 FLAG_SAFE_SORT = 8
 FLAG_COUNTING_SORT_TILES = 16
 FLAG_XCD_EIGHTHS = 64
+FLAG_NO_HALF_TILES = 128
 PIPELINE_COMPAT, PIPELINE_NATIVE = 0, 1
 (REASON_NONE, REASON_MODE_COMPAT, REASON_NO_PARTICLES, REASON_OUT_OF_BOX, REASON_GRID_TOO_WIDE,
  REASON_TABLE_TOO_LARGE, REASON_DENSE_WINDOWS) = range(7)

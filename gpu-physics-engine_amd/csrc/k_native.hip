@@ -82,6 +82,8 @@ constexpr uint32_t kErrTileOverflow = 2u;      // an 8x8 tile region over LDS ca
 constexpr uint32_t kErrBoundExceeded = 16u;    // sharded run: the device-side particle count passed the host's bound
 // tile_ctl words (the first four are cleared every step, the error word is sticky)
 constexpr int kCtlOverflow1 = 0;               // 32x32 tiles over capacity this step
+constexpr int kCtlOverflow2 = 1;               // 32x16 halves of those the half-tile launch could not take either
+constexpr int kCtlHalfTicket = 7;              // next work item of the half-tile launch
 constexpr int kCtlWindowMax = 2;               // largest 24x24-cell window population seen this step
 constexpr int kCtlArena = 3;                   // particles handed out of the global spill arena this step
 constexpr int kCtlOverflowTicket = 4;          // next work item of the over-capacity launch
@@ -597,6 +599,12 @@ struct CollideArgs {
     uint32_t *tile_ctl;          // kCtl* words
     uint32_t *overflow1;         // packed (ty << 16 | tx) of over-capacity 32x32 tiles
     uint32_t overflow1_cap;
+    // While tiles run over the direct-slot form (the host's lagged statistic) a launch between the dense and the
+    // over-capacity one redoes each as two 32x16 HALVES in the same direct-slot form (k_collide_halves: half the cells,
+    // so 1.6 x the particles per cell fit, at the dense launch's cost per particle); the halves it cannot take either
+    // are listed in overflow2 (packed ty16 << 16 | tx32) and the over-capacity launch works through that list.
+    uint32_t *overflow2;
+    uint32_t quarters_of_halves; // the over-capacity launch takes its quarters from overflow2 (two per half), not overflow1
     // spill arena (global memory) for the particle arrays of such tiles
     float *arena_px, *arena_py, *arena_rad;
     uint32_t *arena_id, *arena_hm, *arena_mem;   // arena_mem holds 4 entries per particle
@@ -640,6 +648,10 @@ constexpr int kRosterCap = GPE_QMAX_MAIN_VALUE * 512;   // == TileDirect<32, ..,
 // over-capacity launch cost -- g_tile_cycles[tile of the tile box] = (cycles of the dense launch's workgroup, outcome:
 // 0 done / 1 handed on, cycles of its quarters in the over-capacity launch, particles it looked up)
 __device__ uint4 *g_tile_cycles;
+__device__ uint32_t g_bail_reasons[8];         // why direct-slot tiles were handed on, counted since the last reset
+#define GPE_BAIL(code) atomicAdd(&g_bail_reasons[code], threadIdx.x == 0 ? 1u : 0u)
+#else
+#define GPE_BAIL(code) ((void)0)
 #endif
 #ifdef GPE_DBG_RT
 // diagnostic builds only (scripts/overflow_phases.py): parts of the counting-sort windows' colour passes switched off at
@@ -2058,9 +2070,12 @@ struct TileDirect {
     static constexpr int ZOX = HXL - kConeLeft, ZOY = HYL - kConeDown;   // window coordinate of zone cell (0, 0)
     static constexpr int NBX = (TX + 2 * kHalo) / 8, NBY = (TY + 2 * kHalo) / 8;
     static constexpr int NBLK = NBX * NBY;
-    static constexpr int QMAX = GPE_QMAX_MAIN;
+    // (a 32x16 half looks up 6 x 4 blocks, 3/4 of what a 32x32 tile does, for half the cells: it exists for tiles of up to
+    // ~4 x the benchmark density, so it stages more looked-up particles, side-list entries and whole-wave cells)
+    static constexpr int QMAX = TY >= 32 ? GPE_QMAX_MAIN : 7;
     static constexpr int RAWCAP = QMAX * NT;
-    static constexpr int WC = 16;
+    static constexpr int WC = TY >= 32 ? 16 : 32;
+    static constexpr int kBig = TY >= 32 ? kBigCap : 2 * kBigCap;
     uint32_t lid[LID ? CAP : 1];
     float px[CAP], py[CAP], rad[CAP];
     uint32_t id[CAP];
@@ -2081,10 +2096,9 @@ struct TileDirect {
     union {
         uint16_t list[4 * QZ]; // active cells, one segment per colour (P4 on)
         uint8_t sblk[RAWCAP];  // P0-P1 only: region block a looked-up slot came from
-        static_assert(RAWCAP <= 8 * QZ, "sblk fits under list");
     };
     uint16_t wlist[4 * WC];    // cells of more than kDirectSlots members, per colour
-    uint32_t big[kBigCap];     // memberships that found their cell's slots taken: zone cell << 16 | particle slot
+    uint32_t big[kBig];        // memberships that found their cell's slots taken: zone cell << 16 | particle slot
     uint32_t lcnt[12];
     static constexpr int VBMAX = NBLK;                    // (an order-key window gets its ghosts from the tile's ghost list)
     uint32_t bstart[VBMAX];
@@ -2111,10 +2125,11 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     GPE_STAMP_BEGIN();
     const uint32_t fresh_word = *A.fresh;                              // (issued here, consumed behind P0: see process_tile)
     const uint32_t owned_word = A.counts ? A.counts[0] : (uint32_t)(A.n_owned < 0xFFFFFFFFull ? A.n_owned : 0xFFFFFFFFull);
-    // stragglers handed to this tile by the hash kernel
-    static_assert(TY == 32 && TX == 32, "straggler lists and rosters are kept per 32x32 tile");
-    const bool in_tb = A.tb.holds(tx, ty);                             // (always, for the tiles of the dense launch)
-    const uint32_t pt = in_tb ? A.tb.index(tx, ty) : 0u;
+    // stragglers handed to this tile by the hash kernel (the lists are kept per 32x32 tile: a half reads its parent's)
+    static_assert(TX == 32 && (TY == 32 || TY == 16), "straggler lists, ghost lists and rosters are kept per 32x32 tile");
+    const int ptx = tx, pty = (ty * TY) >> 5;
+    const bool in_tb = A.tb.holds(ptx, pty);                           // (always, for the tiles of the dense launch)
+    const uint32_t pt = in_tb ? A.tb.index(ptx, pty) : 0u;
     const uint32_t exc_word = (A.exc_count && in_tb) ? A.exc_count[pt] : 0u;
     uint32_t gho_word = 0, gsort_word = 0;
     if constexpr (ORD) {
@@ -2122,7 +2137,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         if (A.gho_count && in_tb) gho_word = A.gho_count[pt];
     }
     // the tile's roster (CollideArgs): header, and the first ids on the chance that it is valid
-    constexpr bool kRoster = TX == 32 && NT == 512;
+    constexpr bool kRoster = TX == 32 && TY == 32 && NT == 512;
     constexpr int QP = QMAX >= 2 ? 2 : 1;
     static_assert(!kRoster || L::RAWCAP == kRosterCap, "roster stride");
     const bool rosters = kRoster && A.roster_hdr != nullptr && in_tb;
@@ -2155,7 +2170,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     const bool record = rosters && !listed && A.roster_write != 0u;
     if (listed) {
         const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.x);
-        if (count == 0xFFFFFFFFu) return false;                        // more looked-up particles than the tile stages
+        if (count == 0xFFFFFFFFu) { GPE_BAIL(1); return false; }       // more looked-up particles than the tile stages
         const uint32_t wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);
         if (tid == 0) {
             S.misc[0] = count; S.misc[2] = 0; S.misc[3] = 0; S.misc[4] = 0;
@@ -2229,7 +2244,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         // (A tile that writes a roster goes through the gather for it even when nothing of this step's is its own.)
         if (stale ? (P == 0 && any_exc == 0) : (S.misc[1] == 0 && !(record && P != 0))) return true;
     }
-    if (P > (uint32_t)L::RAWCAP) return false;                         // more looked-up particles than slots
+    if (P > (uint32_t)L::RAWCAP) { GPE_BAIL(1); return false; }        // more looked-up particles than slots
     if (!listed) {
         constexpr int SHARE = (NT / VB) > 0 ? (NT / VB) : 1;
         for (int b = tid % VB, sub = tid / VB; sub < SHARE && b < VB; b += NT) {
@@ -2252,7 +2267,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             if (k < (uint32_t)MS) S.mem[zc * MS + (int)k] = (uint16_t)s;
             else {
                 const uint32_t e = atomicAdd(&S.misc[4], 1u);
-                if (e < (uint32_t)kBigCap) S.big[e] = ((uint32_t)zc << 16) | s;
+                if (e < (uint32_t)L::kBig) S.big[e] = ((uint32_t)zc << 16) | s;
             }
         }
     };
@@ -2392,10 +2407,10 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     __syncthreads();
     GPE_STAMP(1);
     const uint32_t PS = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[3]);
-    if (PS > (uint32_t)L::kSlots) return false;                        // more kept particles than the window stages
+    if (PS > (uint32_t)L::kSlots) { GPE_BAIL(2); return false; }       // more kept particles than the window stages
     if (PS == 0) return true;
     const uint32_t n_big = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.misc[4]);
-    if (n_big > (uint32_t)kBigCap) return false;                       // crowded cells: process_tile's windows take it
+    if (n_big > (uint32_t)L::kBig) { GPE_BAIL(3); return false; }      // crowded cells: process_tile's windows take it
 
     // the tile's own particles and their previous positions: fetched here, used in P6 (as process_tile)
     constexpr int QOWN = (L::kSlots + NT - 1) / NT;
@@ -2473,9 +2488,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
                 single[c] = lanes_of(ms[c]);
                 if (wave_m != 0) {                                     // (scalar: rare)
                     if (lanes_of(wave_m)) {
-                        if (cnt[c] > 64u) S.misc[2] = 1u;              // a pile: the sub-tile windows resolve those
+                        if (cnt[c] > 64u) { S.misc[2] = 1u; GPE_BAIL(4); }   // a pile: the sub-tile windows resolve those
                         const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
-                        if (k < (uint32_t)L::WC) S.wlist[c * L::WC + k] = (uint16_t)zc[c]; else S.misc[2] = 1u;
+                        if (k < (uint32_t)L::WC) S.wlist[c * L::WC + k] = (uint16_t)zc[c]; else { S.misc[2] = 1u; GPE_BAIL(5); }
                     }
                 }
             }
@@ -2663,6 +2678,46 @@ __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide
     }
 }
 
+// (three workgroups per CU: 80 VGPRs and 53 KB of LDS each -- room for 2000 particles, what a half of a tile at ~6 x the
+// benchmark density keeps; an order-key window pays 4 more bytes per particle)
+#ifndef GPE_CAP_HALF
+#define GPE_CAP_HALF 2000
+#endif
+#ifndef GPE_CAP_HALF_ORD
+#define GPE_CAP_HALF_ORD 1680
+#endif
+// The 32x32 tiles the dense launch handed on, each redone as two 32x16 halves in the direct-slot form (CollideArgs::
+// overflow2): a ticketed grid like the over-capacity launch's, only launched while the host's lagged statistic reports
+// such tiles.  A half that does not fit either is listed for the over-capacity launch's 16x16 / 8x8 windows.
+// (Why: one tile a little over 928 particles used to cost the step a whole over-capacity launch -- a counting-sort 16x16
+// window takes ~30 us whatever it holds, behind the dense launch: +40 % on the 1 M step once the undamped benchmark cloud
+// has clumped, from step ~1000 on.  A half costs what a dense-launch tile costs, ~10 us.)
+template <bool ORD>
+__global__ __launch_bounds__(512, 6) void k_collide_halves(CollideArgs A)
+{
+    __shared__ TileDirect<32, 16, ORD ? GPE_CAP_HALF_ORD : GPE_CAP_HALF, ORD, 512> S;
+    __shared__ uint32_t s_item;
+    uint32_t count = A.tile_ctl[kCtlOverflow1];
+    if (count > A.overflow1_cap) count = A.overflow1_cap;
+    const uint32_t work = count * 2u;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&A.tile_ctl[kCtlHalfTicket], 1u);
+        __syncthreads();
+        const uint32_t i = s_item;
+        __syncthreads();
+        if (i >= work) break;
+        const uint32_t parent = A.overflow1[i >> 1];
+        const int tx = (int)(parent & 0xFFFFu), ty = (int)((parent >> 16) * 2u + (i & 1u));
+        const bool done = process_tile_direct<ORD>(S, A, tx, ty);
+        __syncthreads();
+        if (!done && threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow2], 1u);
+            if (slot < 2u * A.overflow1_cap) A.overflow2[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
+            else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
+        }
+    }
+}
+
 // Over-capacity 32x32 tiles are redone by a fixed grid that takes work items off the device-side list (HIP has no
 // indirect dispatch): one work item per 16x16 quarter.  One launch, nothing to wait for.
 // (Eight waves per SIMD = 64 VGPRs: the kernel spills -- the item loop keeps the arguments of three inlined tile
@@ -2673,9 +2728,11 @@ __global__ __launch_bounds__(kNatThreads, GPE_OVF_WAVES) void k_collide_overflow
 {
     __shared__ OverflowLds<ORD> u;
     __shared__ uint32_t s_item;
-    uint32_t count = A.tile_ctl[kCtlOverflow1];
-    if (count > A.overflow1_cap) count = A.overflow1_cap;
-    const uint32_t work = count * 4u;
+    // work items: the four quarters of every tile of list 1, or the two of every half of list 2 (CollideArgs)
+    const bool halves = A.quarters_of_halves != 0u;
+    uint32_t count = A.tile_ctl[halves ? kCtlOverflow2 : kCtlOverflow1];
+    if (count > (halves ? 2u : 1u) * A.overflow1_cap) count = (halves ? 2u : 1u) * A.overflow1_cap;
+    const uint32_t work = count * (halves ? 2u : 4u);
     if (work == 0) return;
     // Work items are taken from a ticket counter: their durations differ by orders of magnitude (in a compressed scene
     // the lower quarters of a tile hold several times the particles of the upper ones), and a fixed stride of 1024
@@ -2686,14 +2743,17 @@ __global__ __launch_bounds__(kNatThreads, GPE_OVF_WAVES) void k_collide_overflow
         const uint32_t i = s_item;
         __syncthreads();
         if (i >= work) break;
-        const uint32_t parent = A.overflow1[i >> 2];
+        // the quarter, in 16-cell units, and its 32x32 tile
+        uint32_t qx, qy;
+        if (halves) { const uint32_t h = A.overflow2[i >> 1]; qx = (h & 0xFFFFu) * 2u + (i & 1u); qy = h >> 16; }
+        else { const uint32_t parent = A.overflow1[i >> 2]; qx = (parent & 0xFFFFu) * 2u + (i & 1u); qy = (parent >> 16) * 2u + ((i >> 1) & 1u); }
 #ifdef GPE_TILE_CYCLES
         const long long tq0 = clock64();
 #endif
-        resolve_quarter<ORD>(u, A, (int)((parent & 0xFFFFu) * 2u + (i & 1u)), (int)((parent >> 16) * 2u + ((i >> 1) & 1u)));
+        resolve_quarter<ORD>(u, A, (int)qx, (int)qy);
 #ifdef GPE_TILE_CYCLES
-        if (g_tile_cycles && threadIdx.x == 0 && A.tb.holds((int)(parent & 0xFFFFu), (int)(parent >> 16)))
-            atomicAdd(&g_tile_cycles[A.tb.index((int)(parent & 0xFFFFu), (int)(parent >> 16))].z, (uint32_t)(clock64() - tq0));
+        if (g_tile_cycles && threadIdx.x == 0 && A.tb.holds((int)(qx >> 1), (int)(qy >> 1)))
+            atomicAdd(&g_tile_cycles[A.tb.index((int)(qx >> 1), (int)(qy >> 1))].z, (uint32_t)(clock64() - tq0));
 #endif
     }
 }
@@ -3041,7 +3101,7 @@ gpe_status native_configure(gpe_ctx *c)
     if (N.overflow_cap < tiles) {
         if (N.overflow1) GPE_HIP(c, hipFree(N.overflow1));
         N.overflow1 = nullptr; N.overflow_cap = 0;
-        GPE_HIP(c, hipMalloc((void **)&N.overflow1, (tiles + 16) * sizeof(uint32_t)));
+        GPE_HIP(c, hipMalloc((void **)&N.overflow1, (3 * tiles + 32) * sizeof(uint32_t)));   // (the tiles, then their halves: CollideArgs::overflow2)
         N.overflow_cap = tiles;
     }
     {
@@ -3226,6 +3286,8 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.tile_ctl = N.tile_ctl;
     A.overflow1 = N.overflow1;
     A.overflow1_cap = (uint32_t)N.overflow_cap;
+    A.overflow2 = N.overflow1 + N.overflow_cap + 16;
+    A.quarters_of_halves = 0u;
     {
         // arena layout: px | py | rad | id | hm | mem (4 per slot) | sblk
         float *f = (float *)N.arena;
@@ -3275,6 +3337,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.tiles_x = cx1 / kTileMain - A.tile_x0 + 1;
     A.tiles_y = cy1 / kTileMain - A.tile_y0 + 1;
     const uint32_t total = (uint32_t)A.tiles_x * (uint32_t)A.tiles_y;
+    bool direct_form = false;                                          // the dense launch runs direct-slot tiles
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
         // Bands of up to 8 tile rows (at least four bands per XCD where the box has the rows for it), of the height that
@@ -3321,6 +3384,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // looks its ghosts up in the block tables, which only the counting-sort form does)
         const bool legacy = (c->cfg.flags & GPE_FLAG_COUNTING_SORT_TILES) != 0 || N.crowded ||
                             (A.order_keys != nullptr && A.gho_count == nullptr);
+        direct_form = !legacy;
         if (legacy) {
             if (A.order_keys)
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapOrd, true>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
@@ -3344,6 +3408,21 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         Scope s(c, "native/collide-dense-regions");
         if (N.host_stat && N.host_stat[kStatOverflow] != 0) N.quiet_steps = 0;
         else if (N.quiet_steps < 0xFFFFFFFFu) ++N.quiet_steps;
+        // The half-tile launch: while the direct-slot launch has handed tiles on lately (lagged; either way is exact --
+        // without it the over-capacity launch takes the tiles of list 1).  Not behind counting-sort tiles: what does not
+        // fit their 1192 particles is dense enough for the windows.
+        // (A scene in which more than 2 % of the tiles run over has its dense launch on counting-sort tiles by then --
+        // `crowded` above: this launch is for the few tiles of a clumped cloud, not for piles; keeping the direct-slot form
+        // with halves behind it up to 50 % of the tiles was measured: step 2000 of the 100 M soak 35.5 instead of 31.0 ms.)
+        if (direct_form && N.quiet_steps < 32u && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0) {
+            A.quarters_of_halves = 1u;
+            const uint32_t hgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, 2ull * N.host_stat[kStatOverflow] + 32));
+            if (A.order_keys)
+                hipLaunchKernelGGL(k_collide_halves<true>, dim3(hgrid), dim3(512), 0, c->stream, A);
+            else
+                hipLaunchKernelGGL(k_collide_halves<false>, dim3(hgrid), dim3(512), 0, c->stream, A);
+            GPE_HIP(c, hipGetLastError());
+        }
         // (Only where the empty launch matters: from a few million particles on its 6 us are noise, and a surprise -- the
         // statistic lags by up to 64 steps -- would cost those steps milliseconds each.)
         const uint32_t ogrid = (N.quiet_steps > 96 && c->n <= (4ull << 20)) ? 128u : 1024u;
@@ -3436,6 +3515,21 @@ extern "C" gpe_status gpe_debug_tile_cycles(gpe_ctx *c, uint32_t *out, uint64_t 
     }
     if (!buf || words < tiles * 4) return GPE_ERR_INVALID_ARG;
     (void)hipMemcpy(out, buf, tiles * sizeof(uint4), hipMemcpyDeviceToHost);
+    return GPE_OK;
+}
+#endif
+
+#ifdef GPE_TILE_CYCLES
+// diagnostic builds only: how often each reason handed a direct-slot tile on since the last call (1 looked up > 1536,
+// 2 kept > capacity, 3 more than kBigCap memberships beyond a cell's slots, 4 a cell of more than 64 (lanes counted),
+// 5 more than 16 cells of 7+ members in a colour (lanes counted))
+extern "C" gpe_status gpe_debug_bail_reasons(gpe_ctx *c, uint32_t *out8)
+{
+    if (!c || !out8) return GPE_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(gpe::g_bail_reasons), 8 * sizeof(uint32_t));
+    uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(gpe::g_bail_reasons), z, sizeof(z));
     return GPE_OK;
 }
 #endif

@@ -80,8 +80,10 @@ enum {
                                      /* (k_radix_sort.hip) instead of onesweep: an in-GPU cross-check                */
     GPE_FLAG_COUNTING_SORT_TILES = 16u, /* NATIVE: the dense launch builds its member lists by a counting sort      */
                                      /* (rounds 1-2) instead of direct cell slots; for A/B timing                    */
-    GPE_FLAG_XCD_EIGHTHS = 64u       /* NATIVE: every XCD works through one contiguous eighth of the tile rows       */
+    GPE_FLAG_XCD_EIGHTHS = 64u,      /* NATIVE: every XCD works through one contiguous eighth of the tile rows       */
                                      /* (rounds 1-3) instead of interleaved bands of rows; for A/B timing            */
+    GPE_FLAG_NO_HALF_TILES = 128u    /* NATIVE: tiles the direct-slot launch hands on go straight to the 16x16 / 8x8 */
+                                     /* windows (rounds 1-3), not first through 32x16 direct-slot halves; A/B timing */
 };
 
 /* Fills *cfg with the reference's compile-time constants. */

@@ -630,6 +630,48 @@ def test_other_tile_forms_give_the_same_bits(gpe, oracle, flag):
     a.close(); b.close(); sim.close()
 
 
+def test_half_tiles_take_what_runs_over_the_direct_slot_form(gpe, oracle):
+    """A patch of 3 x 3 tiles at 1.9 x the benchmark density (they keep ~1090 particles: more than the direct-slot form's
+    928) and a small blob crowded far beyond that, in an otherwise ordinary cloud -- fewer than 2 % of the tiles, so the
+    dense launch stays on direct-slot tiles and hands those few on: the half-tile launch (round 4) resolves the patch as
+    32 x 16 direct-slot halves and passes the blob's halves on to the 16 x 16 / 8 x 8 windows.  Bit-identical to a run
+    without that launch (GPE_FLAG_NO_HALF_TILES: rounds 1-3, where every such tile went to the windows) and to the oracle;
+    gravity moves the cloud across tile and half boundaries."""
+    n = 200_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=23)
+    rng = np.random.default_rng(24)
+    side = np.float32(3 * 32 * 1.1)
+    extra = int(0.9 * 0.3131 * float(side) ** 2)           # + 0.9 x the benchmark density on the patch
+    patch = (np.array([400.0, 150.0], np.float32) + rng.random((extra, 2), dtype=np.float32) * side).astype(np.float32)
+    blob = (np.array([900.0, 40.0], np.float32) + rng.random((1500, 2), dtype=np.float32) * np.float32(20.0)).astype(np.float32)
+    pos = np.concatenate([pos, patch, blob]).astype(np.float32)
+    rad = np.full(len(pos), 0.5, np.float32)
+    g = (2.0, -9.81)
+    a = gpe.State(pos, rad, world=world, gravity=g)
+    b = gpe.State(pos, rad, world=world, gravity=g, flags=gpe._lib.FLAG_NO_HALF_TILES)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5, gravity=g))
+    oracle.set_threads(8)
+    over = []
+    try:
+        for s in range(30):
+            rs = s in (0, 20)
+            a.update(1 / 60, resort=rs); b.update(1 / 60, resort=rs); sim.step(1 / 60, resort=rs)
+            a.ctx.sync()
+            over.append(a.ctx.pipeline_info()["overflow_tiles"])
+            if s % 6 == 5:
+                pa = a.positions()
+                assert np.array_equal(pa, b.positions()), "step %d" % s
+                _assert_positions(pa, sim.pos, "half tiles vs oracle, step %d" % s)
+    finally:
+        oracle.set_threads(1)
+    tiles = (int(world[0] / 1.1) // 32 + 1) * (int(world[1] / 1.1) // 32 + 1)
+    assert max(over) >= 6 and max(over) <= tiles // 50 + 4, (over, tiles)    # tiles were handed on, and few enough
+    assert np.array_equal(a.previous_positions(), b.previous_positions())
+    assert a.ctx.pipeline_info()["compat_steps"] == 0
+    a.close(); b.close(); sim.close()
+
+
 def test_stragglers_flying_into_empty_space_are_not_lost(gpe, oracle):
     """A few very fast particles shot out of a compact cloud into an otherwise empty world: their tiles look nothing up
     (no block of the kept table lies near them), so they exist for those tiles only through the straggler lists.  Exact
