@@ -557,6 +557,7 @@ gpe_status gpe_sync(gpe_ctx *c)
 {
     if (!c) return GPE_ERR_INVALID_ARG;
     GPE_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->shard.xstream) GPE_HIP(c, hipStreamSynchronize(c->shard.xstream));   // (a sharded run's exchange stream)
     return check_device_errors(c);
 }
 

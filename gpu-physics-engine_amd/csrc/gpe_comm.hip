@@ -137,6 +137,7 @@ gpe_status rccl_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_
 
 }  // namespace gpe
 
+namespace gpe { gpe_status exchange_on(gpe_ctx *c, hipStream_t xs); }
 using namespace gpe;
 
 extern "C" {
@@ -214,8 +215,25 @@ gpe_status gpe_shard_exchange(gpe_ctx *c)
     if (!S.packed) return fail(c, GPE_ERR_STATE, "gpe_shard_exchange: nothing was packed (gpe_shard_begin / gpe_shard_step)");
     GPE_HIP(c, hipSetDevice(c->device));
     Scope s(c, "shard/exchange");
+    // The stream the segments move on: the context's, or -- ShardState::overlap -- one of its own that waits for the
+    // pack (the tiles along the rank's border, native_collide) and is waited for by the next unpack.
+    const hipStream_t xs = S.exchange_stream(c->stream);
+    const bool beside = xs != c->stream;
+    if (beside && S.packed_recorded) GPE_HIP(c, hipStreamWaitEvent(xs, S.ev_packed, 0));
+    gpe_status st = exchange_on(c, xs);
+    if (st == GPE_OK && beside) { GPE_HIP(c, hipEventRecord(S.ev_exchanged, xs)); S.exchanged_recorded = true; }
+    return st;
+}
+
+}  // extern "C"
+
+namespace gpe {
+
+gpe_status exchange_on(gpe_ctx *c, hipStream_t xs)
+{
+    ShardState &S = c->shard;
     if (S.transport) {
-        const int32_t rc = S.transport(S.transport_user, S.send, S.recv, (void *)c->stream);
+        const int32_t rc = S.transport(S.transport_user, S.send, S.recv, (void *)xs);
         if (rc != 0) return fail(c, GPE_ERR_HIP, "gpe_shard_exchange: the caller's transport failed");
         return GPE_OK;
     }
@@ -224,8 +242,8 @@ gpe_status gpe_shard_exchange(gpe_ctx *c)
     if (c->ctl.ready && S.send == c->ctl.d_send) {
         if (c->ctl.coll_set)
             return coll_all_to_all_u32(c, c->ctl.d_send, c->ctl.x_send_off, c->ctl.x_send_cnt, c->ctl.d_recv, c->ctl.x_recv_off,
-                                       c->ctl.x_recv_cnt);
-        if (c->ctl.group) return group_exchange_segments(c);
+                                       c->ctl.x_recv_cnt, xs);
+        if (c->ctl.group) return group_exchange_segments(c, xs);
     }
     if (!S.comm)
         return fail(c, GPE_ERR_STATE, "gpe_shard_exchange: no communicator (gpe_shard_comm_init / _attach) and no transport");
@@ -238,11 +256,10 @@ gpe_status gpe_shard_exchange(gpe_ctx *c)
     for (uint32_t k = 0; k + 1 < S.slots.n_slots; ++k) {
         const int peer = (int)S.slots.rank[k];
         ncclResult_t r = api->Send(S.send + S.slots.send_off[k],
-                                   segment_words(S.slots.send_cap_mig[k], S.slots.send_cap_gho[k]), ncclUint32, peer, comm,
-                                   c->stream);
+                                   segment_words(S.slots.send_cap_mig[k], S.slots.send_cap_gho[k]), ncclUint32, peer, comm, xs);
         if (r == ncclSuccess)
             r = api->Recv(S.recv + S.slots.recv_off[k],
-                          segment_words(S.slots.recv_cap_mig[k], S.slots.recv_cap_gho[k]), ncclUint32, peer, comm, c->stream);
+                          segment_words(S.slots.recv_cap_mig[k], S.slots.recv_cap_gho[k]), ncclUint32, peer, comm, xs);
         if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r;
     }
     const ncclResult_t end = api->GroupEnd();                      // always close the group
@@ -250,6 +267,10 @@ gpe_status gpe_shard_exchange(gpe_ctx *c)
     if (end != ncclSuccess) return fail(c, GPE_ERR_HIP, std::string("ncclGroupEnd: ") + api->GetErrorString(end));
     return GPE_OK;
 }
+
+}  // namespace gpe
+
+extern "C" {
 
 gpe_status gpe_shard_run(gpe_ctx *c, float dt, uint64_t steps)
 {

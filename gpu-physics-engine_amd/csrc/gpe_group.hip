@@ -132,7 +132,9 @@ gpe_status group_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64
 // The neighbour segments of one step: every rank pulls its neighbours' packed segments into its receive buffer.
 // Ordered by events on the contexts' streams -- rank r's copies wait for the pack of each neighbour, and r's next pack
 // waits until every neighbour has copied -- so the host threads only meet, they never wait for the device.
-gpe_status group_exchange_segments(gpe_ctx *c)
+// xs: the stream the copies run on (the context's, or the exchange's own: ShardState::overlap); the pack that follows is
+// always on the context's stream.
+gpe_status group_exchange_segments(gpe_ctx *c, hipStream_t xs)
 {
     gpe_local_group *g = c->ctl.group;
     const uint32_t me = c->ctl.group_rank;
@@ -141,7 +143,7 @@ gpe_status group_exchange_segments(gpe_ctx *c)
     hipError_t e = hipSuccess;
     if (!mine.packed) e = hipEventCreateWithFlags(&mine.packed, hipEventDisableTiming);
     if (e == hipSuccess && !mine.copied) e = hipEventCreateWithFlags(&mine.copied, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(mine.packed, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(mine.packed, xs);
     mine.send = T.d_send; mine.send_off = T.x_send_off; mine.send_cnt = T.x_send_cnt;
     if (e != hipSuccess) { (void)gpe_local_group_abort(g); return fail(c, GPE_ERR_HIP, std::string("local group: exchange: ") + hipGetErrorName(e)); }
     if (!rendezvous(g)) return group_fail(c, "exchange");
@@ -150,12 +152,12 @@ gpe_status group_exchange_segments(gpe_ctx *c)
         if (T.x_recv_cnt[p] == 0) continue;
         const gpe_local_group::Post &P = g->post[p];
         if (P.send_cnt[me] != T.x_recv_cnt[p]) { mismatch = true; break; }
-        e = hipStreamWaitEvent(c->stream, P.packed, 0);
+        e = hipStreamWaitEvent(xs, P.packed, 0);
         if (e == hipSuccess)
             e = hipMemcpyAsync(T.d_recv + T.x_recv_off[p], P.send + P.send_off[me], T.x_recv_cnt[p] * sizeof(uint32_t),
-                               hipMemcpyDeviceToDevice, c->stream);
+                               hipMemcpyDeviceToDevice, xs);
     }
-    if (e == hipSuccess) e = hipEventRecord(mine.copied, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(mine.copied, xs);
     if (mismatch || e != hipSuccess) {
         (void)gpe_local_group_abort(g);
         return fail(c, mismatch ? GPE_ERR_INVALID_ARG : GPE_ERR_HIP,

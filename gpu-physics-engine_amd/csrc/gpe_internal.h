@@ -392,7 +392,8 @@ struct PackArgs {
     // the tiles: a new position inside the `safe` box (world units: the rank's rectangle shrunk by one block + one cell on
     // every side that has a neighbour) concerns no other rank -- its block is this rank's and borders nobody
     float safe_x0 = 0.f, safe_y0 = 0.f, safe_x1 = 0.f, safe_y1 = 0.f;
-    uint32_t on = 0;
+    uint32_t on = 0;                             // 1: pack; 2: this launch runs behind the exchange -- a particle that would
+                                                 // have to be packed is an error (it moved more than a block in one step)
     ShardSlots slots;
 };
 
@@ -473,6 +474,14 @@ struct ShardState {
     uint64_t steps = 0;
     hipEvent_t fence[2] = {nullptr, nullptr};
     bool armed[2] = {false, false};
+    // Exchange beside the step (round 4): the segments move on a stream of their own as soon as the tiles along the rank's
+    // border have packed (ev_packed, recorded on the context's stream), while the interior tiles are still being resolved;
+    // the next unpack waits for ev_exchanged.  overlap == false: everything on the context's stream, in order (rounds 1-3).
+    bool overlap = false;
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;
+    bool packed_recorded = false, exchanged_recorded = false;
+    hipStream_t exchange_stream(hipStream_t main) const { return overlap && xstream ? xstream : main; }
     // moving the segments between ranks (gpe_comm.hip): an RCCL communicator or a caller-supplied transport
     void *comm = nullptr;            // ncclComm_t
     bool comm_owned = false;
@@ -664,7 +673,8 @@ void shard_pack_args(gpe_ctx *c, PackArgs *P);
 // collectives of a sharded run, carried by (in this order) the caller's callbacks, the local group, the RCCL communicator
 gpe_status coll_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op);
 gpe_status coll_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
-                               uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt);
+                               uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt,
+                               hipStream_t on = nullptr);   // (on: the stream handed to the caller's callback; default the context's)
 // the same over the RCCL communicator (gpe_comm.hip) and over a local group (gpe_group.hip)
 gpe_status rccl_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op);
 gpe_status rccl_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
@@ -672,7 +682,7 @@ gpe_status rccl_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_
 gpe_status group_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint32_t op);
 gpe_status group_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
                                 uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt);
-gpe_status group_exchange_segments(gpe_ctx *c);   // the per-step neighbour exchange, event-ordered (no stream sync)
+gpe_status group_exchange_segments(gpe_ctx *c, hipStream_t xs);   // the per-step neighbour exchange, event-ordered (no stream sync)
 void group_leave(gpe_ctx *c);
 gpe_status resort_for_shard(gpe_ctx *c);          // ParticleSort::sort on the owned particles (gpe_api.hip do_resort)
 gpe_status shard_ensure_flag_capacity(gpe_ctx *c);

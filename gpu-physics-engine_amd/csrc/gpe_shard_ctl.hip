@@ -156,11 +156,11 @@ gpe_status coll_all_reduce_u32(gpe_ctx *c, uint32_t *d_buf, uint64_t count, uint
 }
 
 gpe_status coll_all_to_all_u32(gpe_ctx *c, const uint32_t *d_send, const uint64_t *send_off, const uint64_t *send_cnt,
-                               uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt)
+                               uint32_t *d_recv, const uint64_t *recv_off, const uint64_t *recv_cnt, hipStream_t on)
 {
     if (c->ctl.coll_set) {
         if (!c->ctl.coll.all_to_all_u32) return fail(c, GPE_ERR_STATE, "sharded run: the caller's collectives have no all_to_all_u32");
-        if (c->ctl.coll.all_to_all_u32(c->ctl.coll.user, d_send, send_off, send_cnt, d_recv, recv_off, recv_cnt, (void *)c->stream) != 0)
+        if (c->ctl.coll.all_to_all_u32(c->ctl.coll.user, d_send, send_off, send_cnt, d_recv, recv_off, recv_cnt, (void *)(on ? on : c->stream)) != 0)
             return fail(c, GPE_ERR_HIP, "sharded run: the caller's all_to_all_u32 failed");
         return GPE_OK;
     }

@@ -594,6 +594,9 @@ struct CollideArgs {
     int32_t gx, gy;              // cell box
     int32_t tiles_x, tiles_y;    // tile grid of the dense launch
     uint32_t band_rows;          // ... dealt to the XCDs in bands of this many tile rows (dense_launch_tile)
+    // sharded runs that exchange beside the step: the FRAME of the tile grid (frame_l / _r columns, frame_b / _t rows: the
+    // tiles whose particles can come to lie outside the pack's safe box) is resolved first, by k_collide_border
+    int32_t frame_l, frame_r, frame_b, frame_t;
     int32_t tile_x0, tile_y0;    // its first tile (sharded runs cut the grid to the rank's active box)
     const uint32_t *order_keys;  // sharded runs: in-cell order by order_keys[local index]; else NULL
     uint32_t *tile_ctl;          // kCtl* words
@@ -639,6 +642,13 @@ __device__ __forceinline__ void pack_if_near_border(const PackArgs &P, const boo
 {
     const bool near = mine && (o.x < P.safe_x0 || o.x >= P.safe_x1 || o.y < P.safe_y0 || o.y >= P.safe_y1);
     if (ballot64(near) == 0) return;
+    if (P.on == 2u) {
+        // an interior tile, resolved while the segments are already on their way: its particles lie more than a block
+        // (+ a cell) inside the safe box at the start of the step, so only a particle that moved further than the
+        // exchange's protocol allows (one block per step, k_shard.hip) gets here -- the run is in error, loudly
+        if (near) atomicOr(P.err, kShardErrNoSlot);
+        return;
+    }
     pack_particle(P, near, id, o, c, rad, key, cell_size);
 }
 constexpr int kRosterCap = GPE_QMAX_MAIN_VALUE * 512;   // == TileDirect<32, .., 512>::RAWCAP
@@ -2658,6 +2668,34 @@ __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
     }
 }
 
+// The frame of a sharded rank's tile grid (CollideArgs::frame_*), one workgroup per tile: the tiles whose particles may
+// have to be packed for the neighbours.  Launched BEFORE the interior tiles so that the exchange can start while those
+// are resolved; everything such a tile needs happens in this launch -- a tile the direct-slot form has no room for is
+// redone on the spot as four 16x16 quarters (the over-capacity launch would pack its particles after the segments left).
+template <bool ORD>
+__global__ __launch_bounds__(512, 6) void k_collide_border(CollideArgs A)
+{
+    __shared__ union { TileDirect<32, 32, ORD ? GPE_CAP_DIRECT_ORD : GPE_CAP_DIRECT, ORD, 512> tile; OverflowLds<ORD> windows; } u;
+    // frame tile t: the bottom rows, the top rows, then the left and right columns of the rows between
+    const uint32_t nx = (uint32_t)A.tiles_x, ny = (uint32_t)A.tiles_y;
+    const uint32_t fb = (uint32_t)A.frame_b, ft = (uint32_t)A.frame_t, fl = (uint32_t)A.frame_l, fr = (uint32_t)A.frame_r;
+    uint32_t t = blockIdx.x, x, y;
+    if (t < fb * nx) { x = t % nx; y = t / nx; }
+    else if (t < (fb + ft) * nx) { t -= fb * nx; x = t % nx; y = ny - ft + t / nx; }
+    else {
+        t -= (fb + ft) * nx;
+        const uint32_t w = fl + fr;
+        if (w == 0 || t / w >= ny - fb - ft) return;
+        const uint32_t col = t % w;
+        x = col < fl ? col : nx - fr + (col - fl);
+        y = fb + t / w;
+    }
+    const int tx = A.tile_x0 + (int)x, ty = A.tile_y0 + (int)y;
+    if (process_tile_direct<ORD>(u.tile, A, tx, ty)) return;
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) resolve_quarter<ORD>(u.windows, A, tx * 2 + (q & 1), ty * 2 + (q >> 1));
+}
+
 // Level 0: one workgroup per 32x32 tile, tiles dealt so that each XCD (blockIdx % 8) works through a
 // contiguous run of tile rows (neighbouring tiles share halo particles in that XCD's L2).
 template <int T, int CAP, bool ORD>
@@ -3305,6 +3343,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.fuse_verlet = verlet ? 1u : 0u;
     if (verlet) A.vp = *verlet; else memset(&A.vp, 0, sizeof(A.vp));
     A.stamps = nullptr;
+    A.frame_l = A.frame_r = A.frame_b = A.frame_t = 0;
     A.pack = PackArgs();
     if (c->shard.on && c->shard.active && c->shard.have_rect && verlet && A.order_keys) shard_pack_args(c, &A.pack);
 #ifdef GPE_TILE_STAMPS
@@ -3391,7 +3430,46 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
             else
                 hipLaunchKernelGGL((k_collide_dense<kTileMain, kCapMain, false>), dim3(grid), dim3(kNatThreads), 0, c->stream, A);
         } else if (A.order_keys) {
-            hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
+            // A sharded step whose tiles pack (A.pack.on) and whose exchange runs beside it (ShardState::overlap): the frame
+            // of the tile grid first -- the tiles whose particles can come to lie outside the pack's safe box: their cells
+            // reach within a block and a cell (the most a particle may move per step, + the box's margin) of it -- then
+            // the event the exchange waits for, then the interior tiles, which must not have anything to pack.
+            ShardState &SH = c->shard;
+            bool split = false;
+            if (A.pack.on == 1u && SH.overlap && SH.ev_packed) {
+                const int reach = 8 + 1 + 8 + 1;                       // cells: from a tile's edge to the safe box's edge
+                const int rx0 = SH.rect[0] * 8, ry0 = SH.rect[1] * 8, rx1 = SH.rect[2] * 8, ry1 = SH.rect[3] * 8;
+                const bool nb_l = SH.rect[0] > 0, nb_r = SH.rect[2] < SH.blocks_x, nb_d = SH.rect[1] > 0, nb_u = SH.rect[3] < SH.blocks_y;
+                int fl = 0, fr = 0, fb = 0, ft = 0;
+                for (int t = 0; t < A.tiles_x; ++t) {
+                    const int c0 = (A.tile_x0 + t) * kTileMain, c1 = c0 + kTileMain - 1;
+                    if (nb_l && c0 < rx0 + reach) fl = t + 1;
+                    if (nb_r && c1 >= rx1 - reach && fr == 0) fr = A.tiles_x - t;
+                }
+                for (int t = 0; t < A.tiles_y; ++t) {
+                    const int c0 = (A.tile_y0 + t) * kTileMain, c1 = c0 + kTileMain - 1;
+                    if (nb_d && c0 < ry0 + reach) fb = t + 1;
+                    if (nb_u && c1 >= ry1 - reach && ft == 0) ft = A.tiles_y - t;
+                }
+                if (fl + fr < A.tiles_x && fb + ft < A.tiles_y) {
+                    split = true;
+                    A.frame_l = fl; A.frame_r = fr; A.frame_b = fb; A.frame_t = ft;
+                    const uint32_t frame = (uint32_t)((fb + ft) * A.tiles_x + (A.tiles_y - fb - ft) * (fl + fr));
+                    if (frame) {
+                        hipLaunchKernelGGL(k_collide_border<true>, dim3(frame), dim3(512), 0, c->stream, A);
+                        GPE_HIP(c, hipGetLastError());
+                    }
+                    GPE_HIP(c, hipEventRecord(SH.ev_packed, c->stream));
+                    SH.packed_recorded = true;
+                    // the interior: a tile box of its own (bands as above), nothing to pack
+                    A.tile_x0 += fl; A.tile_y0 += fb; A.tiles_x -= fl + fr; A.tiles_y -= fb + ft;
+                    A.pack.on = 2u;
+                    const uint32_t igrid = dense_launch_grid((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, A.band_rows);
+                    hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(igrid), dim3(512), 0, c->stream, A);
+                }
+            }
+            if (!split)
+                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         } else {
             hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         }
@@ -3431,6 +3509,11 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         else
             hipLaunchKernelGGL(k_collide_overflow<false>, dim3(ogrid), dim3(kNatThreads), 0, c->stream, A);
         GPE_HIP(c, hipGetLastError());
+    }
+    // (a sharded step that did not split its tiles: everything has packed now)
+    if (A.pack.on == 1u && c->shard.overlap && c->shard.ev_packed) {
+        GPE_HIP(c, hipEventRecord(c->shard.ev_packed, c->stream));
+        c->shard.packed_recorded = true;
     }
     return GPE_OK;
 }

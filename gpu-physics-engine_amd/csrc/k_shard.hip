@@ -237,6 +237,9 @@ void shard_release(gpe_ctx *c)
     if (S.hole_flag) (void)hipFree(S.hole_flag);
     if (S.host_counts) (void)hipHostFree(S.host_counts);
     for (hipEvent_t e : S.fence) if (e) (void)hipEventDestroy(e);
+    if (S.ev_packed) (void)hipEventDestroy(S.ev_packed);
+    if (S.ev_exchanged) (void)hipEventDestroy(S.ev_exchanged);
+    if (S.xstream) (void)hipStreamDestroy(S.xstream);
     S = ShardState();
 }
 
@@ -311,12 +314,15 @@ static gpe_status launch_pack(gpe_ctx *c, bool reset_headers)
                        c->cell_size, P);
     GPE_HIP(c, hipGetLastError());
     S.packed = true;
+    if (S.overlap) { GPE_HIP(c, hipEventRecord(S.ev_packed, c->stream)); S.packed_recorded = true; }
     return GPE_OK;
 }
 
 static gpe_status launch_unpack(gpe_ctx *c)
 {
     ShardState &S = c->shard;
+    // (the segments arrive on the exchange's stream)
+    if (S.overlap && S.exchanged_recorded) GPE_HIP(c, hipStreamWaitEvent(c->stream, S.ev_exchanged, 0));
     Scope s(c, "shard/unpack");
     uint32_t *old_set = S.counts_now();
     S.parity ^= 1u;                                                    // the kernels behind this launch read the new set
@@ -424,6 +430,24 @@ gpe_status gpe_shard_configure(gpe_ctx *c, const gpe_shard_plan *p)
         S.holes_cap = want;
     }
     GPE_TRY(ensure_flag_capacity(c));
+    // the exchange beside the step: a stream of its own (above the step's priority: its few small operations should not
+    // queue behind two thousand tiles) and the two events that order it with the step
+    if ((c->cfg.flags & GPE_FLAG_SHARD_OVERLAP) != 0 && !S.xstream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipError_t e = hipStreamCreateWithPriority(&S.xstream, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_packed, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_exchanged, hipEventDisableTiming);
+        if (e != hipSuccess) {                                         // (without: everything in order on the one stream)
+            (void)hipGetLastError();
+            if (S.ev_packed) (void)hipEventDestroy(S.ev_packed);
+            if (S.ev_exchanged) (void)hipEventDestroy(S.ev_exchanged);
+            if (S.xstream) (void)hipStreamDestroy(S.xstream);
+            S.xstream = nullptr; S.ev_packed = nullptr; S.ev_exchanged = nullptr;
+        }
+    }
+    S.overlap = S.xstream != nullptr;
+    S.packed_recorded = S.exchanged_recorded = false;
     const bool was_on = S.on;
     S.on = true;
     S.active = false;
@@ -450,6 +474,8 @@ gpe_status gpe_shard_begin(gpe_ctx *c)
     S.begin_epoch = epoch;
     S.active = true;
     S.steps = 0;
+    if (S.xstream) GPE_HIP(c, hipStreamSynchronize(S.xstream));
+    S.packed_recorded = S.exchanged_recorded = false;
     c->native.sort_state_valid = false;       // the caller has just re-sorted / re-dealt the particles: a new grouping
     return launch_pack(c, true);
 }
@@ -510,6 +536,7 @@ gpe_status gpe_shard_counts(gpe_ctx *c, uint64_t *n_owned, uint64_t *n_total, in
     GPE_TRY(shard_ready(c, true));
     ShardState &S = c->shard;
     uint32_t w[5] = {0, 0, 0, 0, 0};
+    if (S.xstream) GPE_HIP(c, hipStreamSynchronize(S.xstream));       // (an exchange nobody unpacked: nothing of it is needed)
     GPE_HIP(c, hipMemcpyAsync(w, S.counts_now(), sizeof(w), hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipMemcpyAsync(&w[kShardError], S.counts + kShardError, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     GPE_HIP(c, hipStreamSynchronize(c->stream));

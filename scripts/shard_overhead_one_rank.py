@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gpe = importlib.import_module("gpu-physics-engine_amd"); L = gpe._lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # gpe_config.flags, e.g. 256 = GPE_FLAG_SHARD_OVERLAP
 world = gpe.scenes.world_for(n)
 pos, rad = gpe.scenes.uniform_cloud(n, world, seed=4)
 
@@ -16,7 +17,7 @@ t0 = time.perf_counter(); plain.run(1 / 60, steps, resort_every=0, resort_first=
 t_plain = (time.perf_counter() - t0) / steps
 plain.close()
 
-st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE); ctx = st.ctx
+st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE, flags=flags); ctx = st.ctx
 st.update(1 / 60, resort=True)
 ctx.call("gpe_use_order_keys", 1)
 cs = np.float32(0.5) * np.float32(2.2)
@@ -52,6 +53,7 @@ t_shard = (time.perf_counter() - t0) / steps
 ctx.set_profiling(True); ctx.reset_timings()
 ctx.call("gpe_shard_run", 1.0 / 60.0, 50); ctx.sync()
 tim = ctx.timings()
+print("flags %d: " % flags, end="")
 print("n=%d  plain %.4f ms/step   sharded loop (RCCL self exchange, %d KB segment) %.4f ms/step   overhead %.1f us" %
       (n, t_plain * 1e3, words * 4 // 1024, t_shard * 1e3, (t_shard - t_plain) * 1e6))
 print("   " + "  ".join("%s %.1fus" % (k, v[0] / max(1, v[1]) * 1e3) for k, v in sorted(tim.items(), key=lambda kv: -kv[1][0])))

@@ -344,17 +344,19 @@ def test_rccl_communicator_in_the_library_single_rank(gpe):
     st.close()
 
 
-def test_rccl_exchange_moves_a_segment_on_hardware(gpe):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_exchange_moves_a_segment_on_hardware(gpe, overlap):
     """gpe_shard_exchange's RCCL path on a real device: a one-rank communicator and a plan whose only "neighbour" is the
     rank itself, so the grouped ncclSend / ncclRecv pair of that slot moves the packed segment from the send buffer
     into the receive buffer through RCCL, on the context's stream -- the call sequence, sizes and offsets of the
-    multi-GPU run, minus the second GPU this box does not have."""
+    multi-GPU run, minus the second GPU this box does not have.  overlap: the same on the exchange's own stream
+    (GPE_FLAG_SHARD_OVERLAP), ordered with the step by the two events."""
     import ctypes as C
     L = gpe._lib
     n = 4000
     world = gpe.scenes.world_for(n)
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=4)
-    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE)
+    st = gpe.State(pos, rad, world=world, mode=gpe.MODE_NATIVE, flags=L.FLAG_SHARD_OVERLAP if overlap else 0)
     ctx = st.ctx
     ctx.call("gpe_use_order_keys", 1)
     cs = np.float32(0.5) * np.float32(2.2)
@@ -567,17 +569,20 @@ def test_migrants_into_a_spill_window_on_a_step_that_keeps_its_table(gpe, tmp_pa
     (8, 120_000, (700.0, 520.0), (15.0, -20.0)),
     (2, 40_000, (420.0, 300.0), (0.0, -80.0)),      # everything falls onto rank 0: buffers grow, the rectangles are re-cut
 ])
-def test_local_group_in_one_process_equals_single_context(gpe, ws, n, world, gravity):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_local_group_in_one_process_equals_single_context(gpe, ws, n, world, gravity, overlap):
     """The sharded run with NO Python in its control plane and no torch anywhere: `ws` contexts of this process, one
     thread each, as a local group (gpe_local_group_*), set up and stepped by gpe_shard_setup / gpe_shard_run_scheduled
     (decomposition, cell size, segments, global re-sort, re-cut: csrc/gpe_shard_ctl.hip).  Bit-identical to the
-    single-context run; the order keys a rank hands back ARE the single-context indices."""
+    single-context run; the order keys a rank hands back ARE the single-context indices.
+    overlap: GPE_FLAG_SHARD_OVERLAP -- the tiles along the rank's border first (k_collide_border), the exchange on a stream
+    of its own beside the interior tiles, the next unpack behind its event."""
     lg = importlib.import_module("gpu-physics-engine_amd.local_group")
     steps, dt, seed, every = 14, 0.05, 5, 6
     if gravity[1] <= -80.0:
         steps, every = 30, 17
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=seed)
-    run = lg.LocalShardedRun(pos, rad, world, ws, gravity=gravity)
+    run = lg.LocalShardedRun(pos, rad, world, ws, gravity=gravity, flags=gpe._lib.FLAG_SHARD_OVERLAP if overlap else 0)
     run.run(dt, steps, resort_every=every, resort_first=True)
     owned = run.owned()
     stats = run.stats()
