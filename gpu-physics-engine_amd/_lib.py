@@ -24,6 +24,7 @@ FLAG_COUNTING_SORT_TILES = 16
 FLAG_XCD_EIGHTHS = 64
 FLAG_NO_HALF_TILES = 128
 FLAG_SHARD_OVERLAP = 256
+FLAG_FUSED_HISTOGRAMS = 512
 PIPELINE_COMPAT, PIPELINE_NATIVE = 0, 1
 (REASON_NONE, REASON_MODE_COMPAT, REASON_NO_PARTICLES, REASON_OUT_OF_BOX, REASON_GRID_TOO_WIDE,
  REASON_TABLE_TOO_LARGE, REASON_DENSE_WINDOWS) = range(7)

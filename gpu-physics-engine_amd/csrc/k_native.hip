@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                                                             uint64_t div_magic, uint32_t *__restrict__ exc_count,
                                                             uint2 *__restrict__ exc_entry,
                                                             uint32_t *__restrict__ exc_count_next, TileBox tb,
-                                                            uint32_t straggler_limit, HashGhosts G)
+                                                            uint32_t straggler_limit, uint32_t fuse_always, HashGhosts G)
 {
     // sorted_key[i] = the block key particle i had when the radix passes last ran (they keep it up to date,
     // k_onesweep.hip): the sorted ids and the block table still describe THAT grouping.  As long as every particle
@@ -350,6 +350,11 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     }
     bool oob = false, drifted = false;
     bool sort_known = sorted_key == nullptr;                           // (wave-uniform) the radix passes will run this step
+    // The digit histograms of the owned particles' keys feed the radix passes -- which run on ~1 % of the steps of a run
+    // that keeps its block table (7-12 % at 100 M in free fall).  Such a run leaves them to a gated launch of its own
+    // behind this kernel (k_native_hist_gated: it returns at once unless need_sort was raised); only a step that sorts
+    // anyway (no kept table: first step, sort_hold, GPE_FLAG_SORT_EVERY_STEP) counts them here, fused.
+    const bool fuse_hist = sorted_key == nullptr || fuse_always != 0u;   // (fuse_always: GPE_FLAG_FUSED_HISTOGRAMS, rounds 1-3)
     for (uint64_t r0 = 0; r0 < rounds; r0 += kHashBatch) {
         float2 p[kHashBatch];
         float rad[kHashBatch];
@@ -449,9 +454,11 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                         }
                 }
             }
+            if (fuse_hist) {                                           // (uniform)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < digits) hist_add(s_hist + q * 256, (key >> (8 * q)) & 255u, valid);
+                for (int q = 0; q < 4; ++q)
+                    if (q < digits) hist_add(s_hist + q * 256, (key >> (8 * q)) & 255u, valid);
+            }
             if (GHOSTS && G.gkeys) {                                   // (uniform)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
     if ((threadIdx.x & 1u) == 0) {
         // two neighbouring bins per 64-bit atomic (no bin reaches 2^32, so nothing carries into the upper one)
         const uint32_t lo = s_hist[threadIdx.x], hi = s_hist[threadIdx.x + 1];   // index = digit * 256 + bin
-        if (lo | hi)
+        if (fuse_hist && (lo | hi))
             __hip_atomic_fetch_add(
                 reinterpret_cast<unsigned long long *>(&hist4[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
                 (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -502,6 +509,38 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
                     reinterpret_cast<unsigned long long *>(&G.ghist_now[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
                     (unsigned long long)glo | ((unsigned long long)ghi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// The digit histograms of the keys when the hash kernel has left them out (a run that keeps its block table): gated like
+// the radix passes behind it -- every workgroup looks at need_sort first and returns at once when no sort is due.  Same
+// layout as the hash's flush (kHistCopies copies of 4 x 256 bins, two bins per 64-bit atomic).
+constexpr int kHistGatedBlock = 1024, kHistGatedGridMax = 512;
+__global__ __launch_bounds__(kHistGatedBlock) void k_native_hist_gated(const uint32_t *__restrict__ keys, uint64_t n, int digits,
+                                                                       uint32_t *__restrict__ hist4,
+                                                                       const uint32_t *__restrict__ need)
+{
+    if (*need == 0u) return;
+    __shared__ uint32_t s_hist[4 * 256];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t idx = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = idx < n;
+        const uint32_t key = valid ? keys[idx] : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < digits) hist_add(s_hist + q * 256, (key >> (8 * q)) & 255u, valid);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 1u) == 0) {
+        const uint32_t lo = s_hist[threadIdx.x], hi = s_hist[threadIdx.x + 1];
+        if (lo | hi)
+            __hip_atomic_fetch_add(
+                reinterpret_cast<unsigned long long *>(&hist4[(blockIdx.x % kHistCopies) * 1024 + threadIdx.x]),
+                (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2930,7 +2969,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
                            N.exc_count ? N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots : nullptr,
                            N.exc_count ? N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles : nullptr, N.tb,
                            (uint32_t)std::max<uint64_t>(64, n >> 11),       // more stragglers than 0.05 % of the particles: sort
-                           hg);
+                           (c->cfg.flags & GPE_FLAG_FUSED_HISTOGRAMS) ? 1u : 0u, hg);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
@@ -2940,6 +2979,12 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         Scope s(c, "native/sort");
         OnesweepGate g;
         g.need = N.tile_ctl + kCtlNeedSort + parity;
+        if (reuse && (c->cfg.flags & GPE_FLAG_FUSED_HISTOGRAMS) == 0) {
+            // (the hash kernel counted nothing: see fuse_hist there)
+            const int hgrid = (int)std::min<uint64_t>(kHistGatedGridMax, std::max<uint64_t>(1, n / (4ull * kHistGatedBlock)));
+            hipLaunchKernelGGL(k_native_hist_gated, dim3(hgrid), dim3(kHistGatedBlock), 0, c->stream, N.keys, n, N.passes, hist_now, g.need);
+            GPE_HIP(c, hipGetLastError());
+        }
         g.fresh = N.tile_ctl + kCtlFresh + parity;
         g.sorts = N.tile_ctl + kCtlSorts;
         g.sorts_seen = N.tile_ctl + kCtlSortsSeen;

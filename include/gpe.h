@@ -84,9 +84,11 @@ enum {
                                      /* (rounds 1-3) instead of interleaved bands of rows; for A/B timing            */
     GPE_FLAG_NO_HALF_TILES = 128u,   /* NATIVE: tiles the direct-slot launch hands on go straight to the 16x16 / 8x8 */
                                      /* windows (rounds 1-3), not first through 32x16 direct-slot halves; A/B timing */
-    GPE_FLAG_SHARD_OVERLAP = 256u    /* sharded runs: the neighbour exchange on a stream of its own beside the       */
+    GPE_FLAG_SHARD_OVERLAP = 256u,   /* sharded runs: the neighbour exchange on a stream of its own beside the       */
                                      /* interior tiles, the tiles along the rank's border first (off by default: on  */
                                      /* one GPU the two cross-stream waits cost more than the exchange they hide)    */
+    GPE_FLAG_FUSED_HISTOGRAMS = 512u /* NATIVE: the hash kernel counts the radix digits every step (rounds 1-3)      */
+                                     /* instead of a gated launch counting them when a sort is due; for A/B timing   */
 };
 
 /* Fills *cfg with the reference's compile-time constants. */

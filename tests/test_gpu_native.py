@@ -596,7 +596,7 @@ def test_pipeline_info_reports_mode_table_and_default(gpe):
     ctx.close()
 
 
-@pytest.mark.parametrize("flag", ["FLAG_COUNTING_SORT_TILES", "FLAG_XCD_EIGHTHS"])
+@pytest.mark.parametrize("flag", ["FLAG_COUNTING_SORT_TILES", "FLAG_XCD_EIGHTHS", "FLAG_FUSED_HISTOGRAMS"])
 def test_other_tile_forms_give_the_same_bits(gpe, oracle, flag):
     """The dense launch has two forms of its tile -- 32 x 32 cells with direct cell slots (the default) and the same
     tile with counting-sort member lists (rounds 1-2, GPE_FLAG_COUNTING_SORT_TILES; what sharded order-key windows and
@@ -604,7 +604,8 @@ def test_other_tile_forms_give_the_same_bits(gpe, oracle, flag):
     boundaries, stragglers, a re-sort, and a crowded corner whose windows go to the over-capacity launch.  (A third
     form, 64 x 32 cells on 1024 threads, was measured slower in round 3 and left the product in round 4:
     profiles/r04/wide_tiles_64x32_removed.patch.)  FLAG_XCD_EIGHTHS: the tiles dealt to the XCDs as one contiguous
-    eighth of the rows each (rounds 1-3) instead of interleaved bands of rows."""
+    eighth of the rows each (rounds 1-3) instead of interleaved bands of rows.  FLAG_FUSED_HISTOGRAMS: the radix digits
+    counted by the hash kernel every step (rounds 1-3) instead of by a gated launch on the steps that sort."""
     n = 150_000
     world = gpe.scenes.world_for(n)
     pos, rad = gpe.scenes.uniform_cloud(n, world, seed=17)
