@@ -1,10 +1,10 @@
-"""profiles/traffic.json from the PMC summaries of scripts/gpu_profile_r03.sh (gpurun_out/r2/prof/pmc_<size>_<counter>.txt).
+"""profiles/traffic.json from the PMC summaries of scripts/gpu_profile_r04.sh (gpurun_out/r04/prof/pmc_<size>_<counter>.txt).
 HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE counts half of a wide coalesced read on gfx950
 (MI355X_MICROARCH.md, HBM; calibrated on k_native_hash / k_verlet in profiles/r01).  Records the csrc digest the numbers
 were measured on; bench.py flags the traffic figure as stale when the kernels have changed since."""
 import hashlib, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03", "prof")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04", "prof")
 SCOPE = {"k_collide_direct": "native/collide+verlet", "k_os_pass<false": "sort/onesweep", "k_native_hash": "native/hash"}
 SIZES = {"1M": 1_000_000, "100M": 100_000_000}
 
@@ -42,7 +42,7 @@ for tag, n in SIZES.items():
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 old = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
 out = {
-    "_about": "HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes, profiles/r03/pmc_*): "
+    "_about": "HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes, profiles/r04/final_pmc_*): "
               "(2 x FETCH_SIZE + WRITE_SIZE) x 1024.  The factor 2 on FETCH_SIZE is MI355X_MICROARCH.md's gfx950 correction, "
               "calibrated in round 1 on kernels of known traffic (k_verlet reads 20 B/particle and reports FETCH_SIZE = 10.0, "
               "k_native_hash reads 8 and reports 4.0; WRITE_SIZE matches their stores exactly).  `sq`: SQ counters per launch "
