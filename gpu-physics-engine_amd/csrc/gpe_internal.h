@@ -318,6 +318,8 @@ struct NativeState {
     bool watch_valid = false;
     uint32_t calm_steps = 0;         // steps without an over-capacity tile or a crowded window while `crowded`
     bool crowded = false;            // many tiles run over the direct-slot form: the dense launch uses the counting-sort form
+    bool hist_fused = false;         // the hash kernel counts the radix digits (most recent steps sorted), not the gated launch
+    uint32_t hist_watch_steps = 0, hist_watch_sorts = 0;
     uint32_t quiet_steps = 0;        // native steps since the tiles last reported an over-capacity 32x32 tile (lagged)
     uint32_t step_seq = 0;           // native_prepare_step calls: its parity selects the per-step control words
     const uint32_t *fresh_word = nullptr;   // tile_ctl word the tiles of the current step read (did the passes run?)

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
 // The digit histograms of the keys when the hash kernel has left them out (a run that keeps its block table): gated like
 // the radix passes behind it -- every workgroup looks at need_sort first and returns at once when no sort is due.  Same
 // layout as the hash's flush (kHistCopies copies of 4 x 256 bins, two bins per 64-bit atomic).
-constexpr int kHistGatedBlock = 1024, kHistGatedGridMax = 512;
+constexpr int kHistGatedBlock = 1024, kHistGatedGridMax = 2048;
 __global__ __launch_bounds__(kHistGatedBlock) void k_native_hist_gated(const uint32_t *__restrict__ keys, uint64_t n, int digits,
                                                                        uint32_t *__restrict__ hist4,
                                                                        const uint32_t *__restrict__ need)
@@ -2925,6 +2925,17 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     const bool reuse = gated && !always_sort && N.sort_state_valid && (kept_sharded || N.sorted_n == n) && !N.always_sort &&
                        N.sort_hold == 0 && N.exc_count != nullptr;     // (no room for the straggler lists: sort every step)
     const uint64_t pairs = ((uint64_t)N.table_entries + 1) / 2;        // the table is allocated in 16-byte units
+    // Who counts the radix digits of a step that keeps its table (k_native_hash, fuse_hist): the hash kernel, fused, while
+    // at least a quarter of the last 16 steps sorted (the passes' own counter, lagged: a falling or crushed cloud before
+    // sort_hold takes over -- the separate launch reads all keys again, 0.2-0.4 ms at 100 M when it runs, against the
+    // 0.075 ms per step the fused count costs the hash);
+    // otherwise the gated launch, which returns at once on the steps that do not sort.
+    if (N.host_stat && ++N.hist_watch_steps >= 16) {
+        const uint32_t sorts = N.host_stat[kStatSorts];
+        N.hist_fused = (sorts - N.hist_watch_sorts) * 4u >= N.hist_watch_steps;
+        N.hist_watch_sorts = sorts; N.hist_watch_steps = 0;
+    }
+    const bool fuse_hist = N.hist_fused || (c->cfg.flags & GPE_FLAG_FUSED_HISTOGRAMS) != 0;
     HashGhosts hg;
     hg.sorted_count = N.tile_ctl + kCtlSortedCount;
     uint64_t g_bound = 0;
@@ -2969,7 +2980,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
                            N.exc_count ? N.exc_entry + (size_t)parity * N.exc_tiles * kExcSlots : nullptr,
                            N.exc_count ? N.exc_count + (size_t)(parity ^ 1u) * N.exc_tiles : nullptr, N.tb,
                            (uint32_t)std::max<uint64_t>(64, n >> 11),       // more stragglers than 0.05 % of the particles: sort
-                           (c->cfg.flags & GPE_FLAG_FUSED_HISTOGRAMS) ? 1u : 0u, hg);
+                           fuse_hist ? 1u : 0u, hg);
         GPE_HIP(c, hipGetLastError());
     }
     uint32_t *sk = nullptr, *sv = nullptr;
@@ -2979,7 +2990,7 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
         Scope s(c, "native/sort");
         OnesweepGate g;
         g.need = N.tile_ctl + kCtlNeedSort + parity;
-        if (reuse && (c->cfg.flags & GPE_FLAG_FUSED_HISTOGRAMS) == 0) {
+        if (reuse && !fuse_hist) {
             // (the hash kernel counted nothing: see fuse_hist there)
             const int hgrid = (int)std::min<uint64_t>(kHistGatedGridMax, std::max<uint64_t>(1, n / (4ull * kHistGatedBlock)));
             hipLaunchKernelGGL(k_native_hist_gated, dim3(hgrid), dim3(kHistGatedBlock), 0, c->stream, N.keys, n, N.passes, hist_now, g.need);
@@ -3038,6 +3049,7 @@ gpe_status native_configure(gpe_ctx *c)
     N.sort_state_valid = false;          // particles, box or keys changed: the kept grouping is of something else
     N.quiet_steps = 0;
     N.crowded = false;
+    N.hist_fused = false; N.hist_watch_steps = 0; N.hist_watch_sorts = N.host_stat ? N.host_stat[kStatSorts] : 0u;
     N.sort_hold = 0; N.watch_steps = 0; N.watch_valid = false;
     N.always_sort = (c->cfg.flags & GPE_FLAG_SORT_EVERY_STEP) != 0;
     N.reason = GPE_REASON_NO_PARTICLES;
