@@ -577,10 +577,10 @@ gpe_status gpe_get_pipeline_info(gpe_ctx *c, gpe_pipeline_info *info)
     out.sort_passes = (uint32_t)N.passes;
     out.native_steps = N.native_steps;
     out.compat_steps = N.compat_steps;
-    out.window_max = N.host_stat ? N.host_stat[0] : 0u;
-    if (N.host_stat) {                                                 // (kStat*, k_native.hip)
-        out.arena_slots = N.host_stat[1]; out.overflow_tiles = N.host_stat[3];
-        out.overflow_subtiles = N.host_stat[4]; out.overflow_spills = N.host_stat[5];
+    if (N.host_stat) {
+        out.window_max = N.host_stat[kStatWindowMax];
+        out.arena_slots = N.host_stat[kStatArena]; out.overflow_tiles = N.host_stat[kStatOverflow];
+        out.overflow_subtiles = N.host_stat[kStatSubTiles]; out.overflow_spills = N.host_stat[kStatSpills];
     }
     if (N.tile_ctl) {
         uint32_t sorts = 0, seen = 0;

@@ -275,6 +275,14 @@ struct TileBox {
     __host__ __device__ __forceinline__ bool holds(int tx, int ty) const { return tx >= x0 && ty >= y0 && tx < x0 + nx && ty < y0 + ny; }
     __host__ __device__ __forceinline__ uint32_t index(int tx, int ty) const { return (uint32_t)(ty - y0) * (uint32_t)nx + (uint32_t)(tx - x0); }
 };
+// pinned host words the native kernels report to (NativeState::host_stat; read by the step policy and by
+// gpe_get_pipeline_info with a lag of the steps in flight)
+constexpr int kStatWindowMax = 0;              // largest 24x24-cell window population of the last native step
+constexpr int kStatArena = 1;                  // spill-arena slots handed out by the last native step
+constexpr int kStatProbe = 2;                  // window population measured by the last asynchronous probe + 1 (0: none yet)
+constexpr int kStatOverflow = 3;               // 32x32 tiles over capacity in the last native step
+constexpr int kStatSubTiles = 4, kStatSpills = 5;   // quarters redone as 8x8 tiles / 8x8 tiles through the arena (diagnostics)
+constexpr int kStatSorts = 6;                  // running count of steps whose radix passes ran (tile_ctl[kCtlSorts]), lagged
 constexpr int kNativeCtlSorts = 14;         // tile_ctl word: running count of steps whose radix passes ran (k_native.hip kCtlSorts)
 constexpr int kNativeCtlSortsSeen = 38;     // its copy in the line the tiles only read (k_native.hip kCtlSortsSeen)
 // Native (N-key sort + LDS cell windows) pipeline state

@@ -134,13 +134,7 @@ static_assert(64 + 2 * kHalo + kDriftLeft + kDriftRight < 128 && 32 + 2 * kHalo 
 // window coordinate of the cell a code names, for a window whose first cell is o (any sign): in [0, 128)
 __device__ __forceinline__ int code_window_x(uint32_t code, int o) { return (int)((code - (uint32_t)o) & kCodeCellMask); }
 __device__ __forceinline__ int code_window_y(uint32_t code, int o) { return (int)(((code >> kCodeYShift) - (uint32_t)o) & kCodeCellMask); }
-// pinned host words the kernels report to (read by the step policy with a lag of the steps in flight)
-constexpr int kStatWindowMax = 0;              // largest 24x24-cell window population of the last native step
-constexpr int kStatArena = 1;                  // spill-arena slots handed out by the last native step
-constexpr int kStatProbe = 2;                  // window population measured by the last asynchronous probe + 1 (0: none yet)
-constexpr int kStatOverflow = 3;               // 32x32 tiles over capacity in the last native step
-constexpr int kStatSubTiles = 4, kStatSpills = 5;   // quarters redone as 8x8 tiles / 8x8 tiles through the arena (diagnostics)
-constexpr int kStatSorts = 6;                  // running count of steps whose radix passes ran (tile_ctl[kCtlSorts]), lagged
+// (the pinned host words the kernels report to -- kStat* -- are declared in gpe_internal.h: gpe_get_pipeline_info reads them too)
 constexpr uint64_t kArenaBytesPerSlot = 37;     // px, py, rad, id, hm (4 B each), 4 member entries (16 B), block (1 B)
 constexpr uint64_t kArenaMaxSlots = 1ull << 30; // the arena's slot numbers are 32 bit; 40 GB of the 288 GB
 // tile sizes (cells) and LDS capacities (particles staged per region)
@@ -915,7 +909,7 @@ __device__ __forceinline__ void sort_members(L &S, const uint32_t b, const uint3
 //    chains, the scalings and the final additions are the same operation on both components, and gfx950 issues
 //    v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 -- IEEE binary32 per component, the same rounding as the scalar
 //    forms -- in the slot of one scalar instruction.  Left to itself hipcc packed a quarter of them.
-//  * the predicates are LANE MASKS (vote_* below): every comparison is voted on its own and the masks are combined
+//  * the predicates are LANE MASKS (ballot64 / lanes_of, gpe_internal.h): every comparison is voted on its own and the masks are combined
 //    by scalar ANDs.  A vote on `a && b` costs two VALU instructions (hipcc materialises the combined predicate as
 //    0 / 1 and compares it again); the response votes three times per pair.
 // `active`: the lanes that have a pair; `plain`: the lanes whose r1 is an ordinary number (1e-30 .. 1e30).  Returns the
