@@ -626,7 +626,7 @@ struct CollideArgs {
     float stiffness;
     int32_t gx, gy;              // cell box
     int32_t tiles_x, tiles_y;    // tile grid of the dense launch
-    uint32_t band_rows;          // ... dealt to the XCDs in bands of this many tile rows (dense_launch_tile)
+    uint32_t band_tiles;         // ... dealt to the XCDs in bands of this many consecutive tiles (dense_launch_tile)
     // sharded runs that exchange beside the step: the FRAME of the tile grid (frame_l / _r columns, frame_b / _t rows: the
     // tiles whose particles can come to lie outside the pack's safe box) is resolved first, by k_collide_border
     int32_t frame_l, frame_r, frame_b, frame_t;
@@ -2653,27 +2653,36 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 // code in profiles/r04/wide_tiles_64x32_removed.patch.)
 // Which tile does workgroup `wg` of the dense launch take?  Workgroups go round the eight XCDs (wg mod 8), and the tiles an
 // XCD works through should be neighbours -- they share halo particles in that XCD's L2 -- so every XCD walks BANDS of
-// A.band_rows tile rows, band b belonging to XCD b mod 8, from the bottom of the box to its top.  (Rounds 1-3 gave each XCD
-// one contiguous eighth of the rows.  A scene stratified in y -- anything under gravity: a crushed pile at the bottom,
-// free fall above, nothing at the top -- then loads the XCDs so unevenly that the launch took twice the time its work
-// amounts to: 6.4 ms for 3.3 ms of workgroup time at step 1250 of the 100 M soak, profiles/r04/tile_cycles_*.txt.)
-// Returns false when the workgroup has no tile.
+// A.band_tiles consecutive tiles (row-major: about two tile rows), band b belonging to XCD b mod 8, from the bottom of the
+// box to its top.  (Rounds 1-3 gave each XCD one contiguous eighth of the rows.  A scene stratified in y -- anything
+// under gravity: a crushed pile at the bottom, free fall above, nothing at the top -- then loads the XCDs so unevenly that
+// the launch took twice the time its work amounts to: 6.4 ms for 3.3 ms of workgroup time at step 1250 of the 100 M
+// soak, profiles/r04/tile_cycles_*.txt.)  Returns false when the workgroup has no tile.
 __device__ __forceinline__ bool dense_launch_tile(const CollideArgs &A, const uint32_t wg, int *tx, int *ty)
 {
     const uint32_t xcd = wg & 7u, j = wg >> 3;
-    const uint32_t band_tiles = A.band_rows * (uint32_t)A.tiles_x;     // tiles of a band
-    const uint32_t band = (j / band_tiles) * 8u + xcd;                 // the j-th tile of this XCD lies in this band
-    const uint32_t t = band * band_tiles + j % band_tiles;
+    const uint32_t band = (j / A.band_tiles) * 8u + xcd;               // the j-th tile of this XCD lies in this band
+    const uint32_t t = band * A.band_tiles + j % A.band_tiles;
     if (t >= (uint32_t)A.tiles_x * (uint32_t)A.tiles_y) return false;
     *tx = A.tile_x0 + (int)(t % (uint32_t)A.tiles_x);
     *ty = A.tile_y0 + (int)(t / (uint32_t)A.tiles_x);
     return true;
 }
-// ... and the grid that covers every tile
-static uint32_t dense_launch_grid(uint32_t tiles_x, uint32_t tiles_y, uint32_t band_rows)
+// The band size for a tile grid: bands a multiple of eight (every XCD the same number, so the busiest XCD has at most a
+// band's remainder more than its share: 30 tile rows of 87 in whole rows give six XCDs 348 tiles and two 261 -- +6.7 % on
+// the busiest against the 326 of an even deal; bands of 82 tiles give 328), about two tile rows each, at least four per XCD.
+static uint32_t dense_launch_band(uint32_t tiles_x, uint32_t tiles_y, bool eighths)
 {
-    const uint32_t bands = (tiles_y + band_rows - 1) / band_rows;
-    return ((bands + 7u) / 8u) * band_rows * tiles_x * 8u;
+    const uint64_t total = (uint64_t)tiles_x * tiles_y;
+    const uint64_t per_xcd = eighths ? 1u : std::max<uint64_t>(4u, (total + 8u * tiles_x) / (16ull * tiles_x));
+    return (uint32_t)std::max<uint64_t>(1u, (total + 8u * per_xcd - 1u) / (8u * per_xcd));
+}
+// ... and the grid that covers every tile
+static uint32_t dense_launch_grid(uint32_t tiles_x, uint32_t tiles_y, uint32_t band_tiles)
+{
+    const uint64_t total = (uint64_t)tiles_x * tiles_y;
+    const uint64_t bands = (total + band_tiles - 1) / band_tiles;
+    return (uint32_t)(((bands + 7u) / 8u) * band_tiles * 8u);
 }
 
 template <int TX, int CAP, bool ORD, int NT>
@@ -3430,27 +3439,8 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     bool direct_form = false;                                          // the dense launch runs direct-slot tiles
     {
         Scope s(c, verlet ? "native/collide+verlet" : "native/collide");
-        // Bands of up to 8 tile rows (at least four bands per XCD where the box has the rows for it), of the height that
-        // leaves the busiest XCD the fewest rows: 298 rows in bands of 8 give five XCDs 40 rows and two 32 -- the launch
-        // then lasts 40 rows, 7 % longer than the 37.25 of an even deal (measured: +4.7 % at 100 M); in bands of 2 the
-        // busiest has 38.
-        {
-            const int most = std::min(8, std::max(1, A.tiles_y / 32));
-            int best_r = 1, best_rows = 1 << 30;
-            for (int r = most; r >= 1; --r) {
-                const int bands = (A.tiles_y + r - 1) / r;
-                int worst = 0;
-                for (int k = 0; k < 8; ++k) {
-                    int rows = 0;
-                    for (int b = k; b < bands; b += 8) rows += std::min(r, A.tiles_y - b * r);
-                    worst = std::max(worst, rows);
-                }
-                if (worst < best_rows) { best_rows = worst; best_r = r; }
-            }
-            A.band_rows = (uint32_t)best_r;
-        }
-        if (c->cfg.flags & GPE_FLAG_XCD_EIGHTHS) A.band_rows = (uint32_t)((A.tiles_y + 7) / 8);   // (rounds 1-3: one band per XCD)
-        const uint32_t grid = dense_launch_grid((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, A.band_rows);
+        A.band_tiles = dense_launch_band((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, (c->cfg.flags & GPE_FLAG_XCD_EIGHTHS) != 0);
+        const uint32_t grid = dense_launch_grid((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, A.band_tiles);
         // Which form of the tile?  The direct-slot form is the faster one while tiles fit it; it holds 928 particles and
         // hands a tile on when its cells crowd (more than 96 memberships beyond a cell's sixth, a cell of more than 64).
         // In a compressed scene (the 100 M cloud after a few hundred steps of gravity) most tiles would take that
@@ -3515,7 +3505,8 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
                     // the interior: a tile box of its own (bands as above), nothing to pack
                     A.tile_x0 += fl; A.tile_y0 += fb; A.tiles_x -= fl + fr; A.tiles_y -= fb + ft;
                     A.pack.on = 2u;
-                    const uint32_t igrid = dense_launch_grid((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, A.band_rows);
+                    A.band_tiles = dense_launch_band((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, (c->cfg.flags & GPE_FLAG_XCD_EIGHTHS) != 0);
+                    const uint32_t igrid = dense_launch_grid((uint32_t)A.tiles_x, (uint32_t)A.tiles_y, A.band_tiles);
                     hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(igrid), dim3(512), 0, c->stream, A);
                 }
             }
