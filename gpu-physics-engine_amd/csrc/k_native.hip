@@ -2097,6 +2097,30 @@ __device__ __forceinline__ void resolve_quarter(OverflowLds<ORD> &u, const Colli
 // compressed scene) is left to process_tile's windows in the over-capacity launch, as is anything else this form has
 // no room for.  Same operations per particle pair in the same order: same bits.
 // ---------------------------------------------------------------------------------------------------
+// The phantom cells of a particle, decoded once: entry[overlap mask] = count (2 bits) | for each of the first three set
+// bits k of the mask (grid.wgsl:68-90 keeps at most three, in scan order: y outer, x inner, centre skipped) dx + 1 (2 bits)
+// and dy + 1 (2 bits).  512 bytes that stay in the vector L1: one load per staged particle instead of find-first-set,
+// clear, the centre skip and a division by three per membership (~7 VALU instructions x 3 memberships x 2 rounds per wave).
+struct PhantomTable { uint16_t v[256]; };
+constexpr PhantomTable make_phantom_table()
+{
+    PhantomTable t{};
+    for (int m = 0; m < 256; ++m) {
+        int cnt = 0, e = 0;
+        for (int k = 0; k < 8 && cnt < 3; ++k) {
+            if (!((m >> k) & 1)) continue;
+            const int kk = k + (k >= 4 ? 1 : 0);
+            e |= ((kk % 3) | ((kk / 3) << 2)) << (2 + 4 * cnt);
+            ++cnt;
+        }
+        t.v[m] = (uint16_t)(e | cnt);
+    }
+    return t;
+}
+__device__ const PhantomTable kPhantomTable = make_phantom_table();
+#ifndef GPE_VAR_PHANTOM_TABLE
+#define GPE_VAR_PHANTOM_TABLE 1
+#endif
 constexpr int kDirectSlots = 6;                // member slots a zone cell owns
 constexpr int kBigCap = 96;                    // memberships beyond that, per tile
 template <int TX_, int TY_, int CAP, bool LID, int NT_>
@@ -2323,6 +2347,15 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         file(zx, zy, s);
         // phantom cells: the first three set bits of the overlap mask (grid.wgsl:68-90 keeps at most three); neighbour
         // k of the scan (y outer, x inner, centre skipped): dx = {-1,0,1,-1,1,-1,0,1}[k], dy = {-1,-1,-1,0,0,1,1,1}[k]
+#if GPE_VAR_PHANTOM_TABLE
+        // (`over` is the particle's entry of kPhantomTable here: the gather looked it up)
+        const int cnt = (int)(over & 3u);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= cnt) break;
+            file(zx - 1 + (int)((over >> (2 + 4 * j)) & 3u), zy - 1 + (int)((over >> (4 + 4 * j)) & 3u), s);
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (over == 0) break;
@@ -2331,6 +2364,16 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             const int kk = k + (k >= 4 ? 1 : 0);                       // position in the 3 x 3 scan with the centre
             file(zx + kk % 3 - 1, zy + kk / 3 - 1, s);
         }
+#endif
+    };
+    // what insert() takes as `over`: the mask itself, or its table entry
+    auto phantoms_of = [&](const uint32_t code) -> uint32_t {
+        const uint32_t mask = (code >> kCodeOverlapShift) & 0xFFu;
+#if GPE_VAR_PHANTOM_TABLE
+        return kPhantomTable.v[mask];
+#else
+        return mask;
+#endif
     };
 #ifdef GPE_DBG_SKIP
     if (!(GPE_DBG_SKIP & 64))                                          // diagnostic builds: phase cost by omission (results wrong)
@@ -2376,6 +2419,9 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
 #pragma unroll
             for (int q = 0; q < QP; ++q) pid[q] = A.order_keys[pid[q]];
         }
+        uint32_t ph[QP];                                               // (issued here: in flight under the keep votes)
+#pragma unroll
+        for (int q = 0; q < QP; ++q) ph[q] = phantoms_of(cc[q]);
         int lxq[QP], lyq[QP];
         bool keep[QP];
         uint32_t slot[QP];
@@ -2405,7 +2451,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         }
 #pragma unroll
         for (int q = 0; q < QP; ++q)
-            if (keep[q]) insert(slot[q], pp[q], pr[q], pid[q], lidq[q], lxq[q], lyq[q], (cc[q] >> kCodeOverlapShift) & 0xFFu);
+            if (keep[q]) insert(slot[q], pp[q], pr[q], pid[q], lidq[q], lxq[q], lyq[q], ph[q]);
     }
     if (n_exc != 0 && tid < 64) {                                      // stragglers handed to the tile (see process_tile)
         const bool have = (uint32_t)tid < n_exc;
@@ -2424,7 +2470,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         const uint32_t sl = base + popc_below_lane(mk);
         keep = keep && sl < (uint32_t)L::kSlots;
-        if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, (cc >> kCodeOverlapShift) & 0xFFu);
+        if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, phantoms_of(cc));
     }
     if constexpr (ORD) {
         // ghosts listed for the tile by the hash kernel (see process_tile)
@@ -2444,7 +2490,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             const uint32_t sl = base + popc_below_lane(mk);
             keep = keep && sl < (uint32_t)L::kSlots;
-            if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, (cc >> kCodeOverlapShift) & 0xFFu);
+            if (keep) insert(sl, pp, pr, pid, lidq, lx, ly, phantoms_of(cc));
         }
     }
     __syncthreads();
