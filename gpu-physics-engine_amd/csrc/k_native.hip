@@ -1373,7 +1373,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // virtual blocks: an order-key (sharded) window looks every block up among the owned particles AND among the ghosts
     constexpr int VB = ORD ? 2 * NBLK : NBLK;
     static_assert(VB <= 255 && VB <= L::VBMAX, "sblk is 8 bit; the lookup arrays hold the virtual blocks");
-    const int tid = (int)threadIdx.x;
+    int tid_ = (int)threadIdx.x;
+    // (the windows of the over-capacity launch run in a loop over tickets: everything that depends on the thread index
+    // alone -- P4's cell coordinates and zone tests, the scans' offsets -- is invariant in that loop, and hipcc hoisted
+    // 37 registers of it in front of the loop, spilled them there and reloaded them inside, s_waitcnt vmcnt(0) behind
+    // each reload; recomputing them per window costs a few VALU instructions)
+    if constexpr (T < 32) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     constexpr int HX = L::HXL, HY = L::HYL;                            // cells kept left of / below the tile
     constexpr bool kTrim = !L::kGlobal;
@@ -1746,9 +1752,13 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
     // (a scalar, so that comparing against it waits for no load: the count of a sharded run is read here, once)
     const uint32_t n_owned = n_owned_now;
     constexpr int QOWN = (L::kSlots + kNatThreads - 1) / kNatThreads;  // ceil(kept capacity / threads)
+    // (The windows of the over-capacity launch fetch at P6 instead: their kernel holds three window forms and the
+    // blocked whole-wave walk, and twelve registers kept across the colour passes were spilled there -- each previous
+    // position right behind its load, s_waitcnt vmcnt(0) in between: P4 took 18.6 k cycles per window instead of 4 k.)
+    constexpr bool kFetchEarly = T >= 32;
     uint32_t own_id[QOWN];
     float2 own_prev[QOWN];
-    if constexpr (kTrim) {
+    if constexpr (kTrim && kFetchEarly) {
         // Branch-free (see P1): every lane loads -- a lane without a particle of the tile reads element 0 -- and
         // the loads of all rounds are issued before anything uses one of them, so they are in flight together and
         // nothing waits for them before P6.
@@ -1944,10 +1954,34 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 
     // ---- P6: write the tile's own particles back ------------------------------------------------------
     const bool packs = ORD && A.pack.on != 0u;                         // (scalar) a sharded step: the tiles pack
+    if constexpr (kTrim && !kFetchEarly) {
+        uint32_t fetch[QOWN];
+#pragma unroll
+        for (int q = 0; q < QOWN; ++q) {
+            const uint32_t s = (uint32_t)tid + (uint32_t)q * kNatThreads;
+            own_id[q] = 0xFFFFFFFFu;
+            fetch[q] = 0u;
+            if (q >= 1 && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar)
+            const uint32_t sc = min(s, PS - 1u);
+            const uint32_t hm = S.hm[sc];
+            const bool own = s < PS && (hm & (1u << 19)) != 0;
+            uint32_t id = S.id[sc];
+            asm volatile("" : "+v"(id));                             // keep this an LDS read (no pointer select -> flat load)
+            if constexpr (ORD) id = S.lid[sc];
+            own_id[q] = own ? id : 0xFFFFFFFFu;
+            fetch[q] = (own && id < n_owned) ? id : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < QOWN; ++q) {
+            own_prev[q] = make_float2(0.f, 0.f);
+            if (q >= 1 && PS <= (uint32_t)q * kNatThreads) continue;
+            if (A.fuse_verlet) own_prev[q] = A.prev[fetch[q]];
+        }
+    }
     if constexpr (kTrim) {
 #pragma unroll
         for (int q = 0; q < QOWN; ++q) {
-            if (q >= 2 && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar, as where own_id was filled)
+            if (q >= (kFetchEarly ? 2 : 1) && PS <= (uint32_t)q * kNatThreads) continue;   // (scalar, as where own_id was filled)
             const uint32_t id = own_id[q];
             const bool have = id != 0xFFFFFFFFu;
             const uint32_t s = min((uint32_t)tid + (uint32_t)q * kNatThreads, (uint32_t)L::kSlots - 1u);
@@ -3454,21 +3488,26 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     if (c->shard.on && c->shard.active && c->shard.have_rect && verlet && A.order_keys) shard_pack_args(c, &A.pack);
 #ifdef GPE_TILE_STAMPS
     static unsigned long long *g_stamps = nullptr;
-    if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 64 * 8); (void)hipMemset(g_stamps, 0, 64 * 8); }
+    // ([0, 64): the dense launch's tiles; [64, 128): the windows of the over-capacity launch)
+    if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 128 * 8); (void)hipMemset(g_stamps, 0, 128 * 8); }
     A.stamps = g_stamps;
     static int g_calls = 0;
-    if (++g_calls % 20 == 0) {
+    if (++g_calls % 20 == 0) for (int part = 0; part < 2; ++part) {
         unsigned long long h[64];
         (void)hipStreamSynchronize(c->stream);
-        (void)hipMemcpy(h, g_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, g_stamps + 64 * part, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, part == 0 ? "[dense launch]\n" : "[over-capacity launch]\n");
         for (int cls = 0; cls < 3; ++cls)
             fprintf(stderr, "[P5 waves] %s: busy %.0f  barrier wait %.0f cycles per colour pass (%llu wave-passes)\n",
                     cls == 0 ? "group waves" : cls == 1 ? "single waves" : "idle waves", h[40 + cls] ? (double)h[32 + cls] / h[40 + cls] : 0.0,
                     h[40 + cls] ? (double)h[36 + cls] / h[40 + cls] : 0.0, h[40 + cls]);
         fprintf(stderr, "[tile stamps] n=%llu", (unsigned long long)c->n);
-        for (int i = 0; i < 14; ++i) fprintf(stderr, "  P%d %.0f", i, h[16 + i] ? (double)h[i] / (double)h[16 + i] : 0.0);
-        fprintf(stderr, "  (tiles %llu)\n", h[16 + 6]);
-        (void)hipMemset(g_stamps, 0, 64 * 8);
+        double all = 0;
+        for (int i = 0; i < 14; ++i) all += (double)h[i];
+        for (int i = 0; i < 14; ++i)
+            fprintf(stderr, "  P%d %.0f (%.1f%%)", i, h[16 + i] ? (double)h[i] / (double)h[16 + i] : 0.0, all > 0 ? 100.0 * (double)h[i] / all : 0.0);
+        fprintf(stderr, "  (tiles %llu of %llu started)\n", h[16 + 6], h[16 + 0]);
+        if (part == 1) (void)hipMemset(g_stamps, 0, 128 * 8);
     }
 #endif
     int32_t cx0 = 0, cy0 = 0, cx1 = N.gx - 1, cy1 = N.gy - 1;
@@ -3592,6 +3631,9 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // (Only where the empty launch matters: from a few million particles on its 6 us are noise, and a surprise -- the
         // statistic lags by up to 64 steps -- would cost those steps milliseconds each.)
         const uint32_t ogrid = (N.quiet_steps > 96 && c->n <= (4ull << 20)) ? 128u : 1024u;
+#ifdef GPE_TILE_STAMPS
+        A.stamps += 64;
+#endif
         if (A.order_keys)
             hipLaunchKernelGGL(k_collide_overflow<true>, dim3(ogrid), dim3(kNatThreads), 0, c->stream, A);
         else
