@@ -791,7 +791,11 @@ struct TileLds {
     // cells of 9..64 members (piles): resolved by a whole wave each; WC per colour, the rest falls back to one lane
     static constexpr int WC = T >= 32 ? 16 : 64;
     uint16_t wlist[4 * WC];
-    uint32_t lcnt[12];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave
+    // cells of 9..16 members of the sub-tile windows: by the sixteen lanes of a DPP row (resolve_row), four per wave
+    static constexpr bool kRows = T < 32;
+    uint16_t rlist[kRows ? 4 * WC : 2];
+    uint32_t lcnt[20];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave, [12 + c] by a
+                               // row; [16 + c] the ticket the waves draw whole-wave cells and quadruples of rows with
     // looked-up blocks; an order-key (sharded) window looks every block up twice: among the owned particles (the kept
     // table) and among the ghosts (their own table, rebuilt every step): virtual blocks [NBLK, 2 NBLK)
     static constexpr int VBMAX = (kLid || kGlobal) ? 2 * NBLK : NBLK;
@@ -835,7 +839,10 @@ struct TileGlobal {
     uint16_t list[4 * QZ];
     static constexpr int WC = 64;
     uint16_t wlist[4 * WC];
-    uint32_t lcnt[12];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave
+    static constexpr bool kRows = true;
+    uint16_t rlist[4 * WC];
+    uint32_t lcnt[20];         // per colour: [c] cells resolved by one lane, [4 + c] by a lane group, [8 + c] by a wave, [12 + c] by a
+                               // row; [16 + c] the ticket the waves draw whole-wave cells and quadruples of rows with
     // looked-up blocks; an order-key (sharded) window looks every block up twice: among the owned particles (the kept
     // table) and among the ghosts (their own table, rebuilt every step): virtual blocks [NBLK, 2 NBLK)
     static constexpr int VBMAX = (kLid || kGlobal) ? 2 * NBLK : NBLK;
@@ -1189,6 +1196,80 @@ __device__ __forceinline__ void resolve_group(L &S, const uint32_t b, const uint
     }
 }
 
+// A cell of 9..16 members resolved by the sixteen lanes of one DPP row: the symmetric walk of resolve_group at twice the
+// width -- the reflection i <-> s - i of a row is row_mirror (i <-> 15 - i) followed by a row shift by |15 - s| -- four
+// cells per wave side by side, 2n - 3 steps of one half-response each.  (Until round 4 these cells went to resolve_wave,
+// one cell per wave, 2n - 2 steps of a whole response and seven wave-wide shifts each: ~15 k cycles for eleven members,
+// and a colour pass of a compressed region's window waits for its slowest wave; phase stamps in profiles/r04.)
+constexpr uint32_t kRowLanes = 16;
+constexpr int kDppRowMirror = 0x140;
+template <int S>
+__device__ __forceinline__ float dpp_reflect_from_row_mirrored(const float m)
+{
+    if constexpr (S < 15) return dpp_mov<0x100 + (15 - S)>(m);        // row_shl: lane i reads lane i + (15 - S)
+    else if constexpr (S > 15) return dpp_mov<0x110 + (S - 15)>(m);   // row_shr: lane i reads lane i - (S - 15)
+    else return m;
+}
+template <int S, bool LOWER = false>
+constexpr uint64_t row_step_lanes()
+{
+    uint64_t m = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int a = lane & 15;
+        if (a <= S && 2 * a != S && (!LOWER || 2 * a < S)) m |= 1ull << lane;
+    }
+    return m;
+}
+template <int K>
+__device__ __forceinline__ uint32_t row_rotated(const uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + K /* row_ror:K */, 0xF, 0xF, false);
+}
+template <int K, int KMAX>
+__device__ __forceinline__ uint32_t row_rank(const uint32_t id)
+{
+    const uint32_t r = row_rotated<K>(id) < id ? 1u : 0u;
+    if constexpr (K < KMAX) return r + row_rank<K + 1, KMAX>(id); else return r;
+}
+// every lane of the wave calls (n == 0: no cell in this row); a = lane & 15
+template <class L>
+__device__ __forceinline__ void resolve_row(L &S, const uint32_t b, const uint32_t n, const int a, const float stiffness)
+{
+    const int row_base = lane_id() & ~((int)kRowLanes - 1);
+    const uint64_t has_m = ballot64((uint32_t)a < n);
+    const bool has = lanes_of(has_m);
+    const uint32_t my_slot = has ? (uint32_t)S.mem[b + a] : 0u;
+    const uint32_t my_id = has ? S.id[my_slot] : 0xFFFFFFFFu;
+    // rank = members of the row with a smaller object index (distinct; lanes without a member hold the largest value)
+    const uint32_t rank = row_rank<1, (int)kRowLanes - 1>(my_id);
+    const uint32_t a_slot = (uint32_t)__builtin_amdgcn_ds_permute((row_base + (int)(has ? rank : (uint32_t)a)) << 2, (int)my_slot);
+    f32x2 o = {0.f, 0.f};
+    float r1 = 1.f;
+    if (has) { o = (f32x2){S.px[a_slot], S.py[a_slot]}; r1 = S.rad[a_slot]; }
+    f32x2 p1 = o;
+    const uint64_t plain = plain_radius_lanes(r1);
+    const float r_mirrored = dpp_mov<kDppRowMirror>(r1);
+    const uint32_t n_plus_a = n + (uint32_t)a;                        // partner s - a exists while s - a < n
+    for_each_group_step<1, 2 * (int)kRowLanes - 3>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int need = (s + 4) / 2;                              // smallest n with 2n - 3 >= s
+        if constexpr (need >= 10) {
+            if ((has_m & ballot64(n >= (uint32_t)need)) == 0) return;  // wave-uniform: no row of the wave is that long
+        }
+        const f32x2 ip = {dpp_reflect_from_row_mirrored<s>(dpp_mov<kDppRowMirror>(p1.x)),
+                          dpp_reflect_from_row_mirrored<s>(dpp_mov<kDppRowMirror>(p1.y))};
+        const float ir = dpp_reflect_from_row_mirrored<s>(r_mirrored);
+        constexpr uint64_t kStepLanes = row_step_lanes<s>();
+        const uint64_t pairing = has_m & kStepLanes & ballot64((uint32_t)s < n_plus_a);
+        constexpr uint64_t kLower = row_step_lanes<s, true>();
+        (void)pair_response<false>(pairing, p1, ip, r1, ir, plain, stiffness, kLower);
+    });
+    if (has && (__float_as_uint(p1.x) != __float_as_uint(o.x) || __float_as_uint(p1.y) != __float_as_uint(o.y))) {
+        S.px[a_slot] = p1.x;
+        S.py[a_slot] = p1.y;
+    }
+}
+
 // A cell of 9..64 members (a pile: particles pressed into one cell) resolved by a whole wave: the systolic array
 // of resolve_group over 64 lanes (wave-wide DPP shifts).  One lane would walk n (n - 1) / 2 pairs one after the
 // other -- 1225 for 50 members, ~0.25 ms, which every colour pass of every tile near the pile would wait for; the
@@ -1404,7 +1485,7 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
 
     // ---- P0: clear, look the region's blocks up, slot -> block map ---------------------------------
     S.cell_clear(tid);
-    if (tid < 12) S.lcnt[tid] = 0;
+    if (tid < 20) S.lcnt[tid] = 0;
     if (tid < VB) {
         const int rb = tid % NBLK;                                     // the block; tid >= NBLK: among the ghosts
         const int bi = rb % NB, bj = rb / NB;
@@ -1843,11 +1924,19 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 if (big_m != 0) {                                      // (scalar: no such cell in most rounds)
                     if (T >= 32 && lanes_of(big_m) && cnt[c] > 64u) S.misc[2] = 1u;
                     bool wavec = lanes_of(wave_m);
+                    bool rowc = false;
+                    if constexpr (L::kRows) {
+                        rowc = wavec && cnt[c] <= kRowLanes;
+                        if (rowc) {
+                            const uint32_t k = atomicAdd(&S.lcnt[12 + c], 1u);
+                            if (k < (uint32_t)WC) { S.rlist[c * WC + k] = (uint16_t)lc[c]; wavec = false; } else rowc = false;
+                        }
+                    }
                     if (wavec) {
                         const uint32_t k = atomicAdd(&S.lcnt[8 + c], 1u);
                         if (k < (uint32_t)WC) S.wlist[c * WC + k] = (uint16_t)lc[c]; else wavec = false;
                     }
-                    wave_m = ballot64(wavec);                          // (cells the wave list had no room for: one lane)
+                    wave_m = ballot64(wavec || rowc);                  // (cells the lists had no room for: one lane)
                 }
                 ms[c] = act_m & ~mg[c] & ~wave_m;
                 group[c] = lanes_of(mg[c]);
@@ -1922,12 +2011,42 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 }
             }
         }
+#ifdef GPE_TILE_STAMPS
+        const long long _tw_cells = clock64();
+#endif
+        // Whole-wave cells and rows: drawn with a ticket, the whole-wave cells (the longest items) first -- the waves that
+        // hold the colour's lane groups or one-lane cells come for them when they are through, the idle ones at once.
+        // (Fixed shares were measured: with the items dealt out from the first wave up the group waves carried them on
+        // top of their groups; from the last wave down the one-lane waves did, and step 2000 of the 100 M soak lost 3 %.)
+        if constexpr (L::kRows) {
+            const uint32_t nr = min(S.lcnt[12 + k], (uint32_t)L::WC);
+            const uint32_t items = nw + (nr + 3u) / 4u;
+            while (items != 0u) {                                         // (wave-uniform)
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(&S.lcnt[16 + k], 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t >= items || GPE_RT_SKIP(4u)) break;
+                if (t < nw) {
+                    const int lc = S.wlist[k * L::WC + t];
+                    const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
+                    if (e - b <= 64u) resolve_wave(S, b, e - b, A.stiffness);
+                    else resolve_wave_blocked(S, b, e - b, A.stiffness);
+                } else {
+                    const uint32_t ci = 4u * (t - nw) + (uint32_t)(lane >> 4);
+                    uint32_t b = 0, e = 0;
+                    if (ci < nr) {
+                        const int lc = S.rlist[k * L::WC + ci];
+                        b = S.cell_get(lc); e = S.cell_get(lc + 1);
+                    }
+                    resolve_row(S, b, e - b, lane & 15, A.stiffness);
+                }
+            }
+        } else
         for (uint32_t i = (uint32_t)(tid >> 6); i < nw; i += kNatWaves) {     // wave-uniform
             if (GPE_RT_SKIP(4u)) break;
             const int lc = S.wlist[k * L::WC + i];
             const uint32_t b = S.cell_get(lc), e = S.cell_get(lc + 1);
             if (e - b <= 64u) resolve_wave(S, b, e - b, A.stiffness);
-            else if constexpr (T < 32) resolve_wave_blocked(S, b, e - b, A.stiffness);
         }
 #ifdef GPE_TILE_STAMPS
         GPE_STAMP(9 + k);
@@ -1941,6 +2060,22 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 atomicAdd(&A.stamps[32 + cls], (unsigned long long)(_tw1 - _tw0));
                 atomicAdd(&A.stamps[36 + cls], (unsigned long long)(_tw2 - _tw1));
                 atomicAdd(&A.stamps[40 + cls], 1ull);
+                // the colour pass by class of cell: cells, and this wave's cycles in the whole-wave cells
+                atomicAdd(&A.stamps[48], (unsigned long long)(_tw1 - _tw_cells));
+                if (w == 0) {
+                    atomicAdd(&A.stamps[44], (unsigned long long)ns);
+                    atomicAdd(&A.stamps[45], (unsigned long long)(group_lanes / kGroupLanes));
+                    atomicAdd(&A.stamps[46], (unsigned long long)nw);
+                    atomicAdd(&A.stamps[47], 1ull);
+                    uint32_t members = 0, largest = 0;
+                    for (uint32_t i = 0; i < nw; ++i) {
+                        const int lc = S.wlist[k * L::WC + i];
+                        const uint32_t m = S.cell_get(lc + 1) - S.cell_get(lc);
+                        members += m; largest = max(largest, m);
+                    }
+                    atomicAdd(&A.stamps[49], (unsigned long long)members);
+                    atomicAdd(&A.stamps[50], (unsigned long long)largest);
+                }
             }
         }
 #else
@@ -3502,6 +3637,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
                     cls == 0 ? "group waves" : cls == 1 ? "single waves" : "idle waves", h[40 + cls] ? (double)h[32 + cls] / h[40 + cls] : 0.0,
                     h[40 + cls] ? (double)h[36 + cls] / h[40 + cls] : 0.0, h[40 + cls]);
         fprintf(stderr, "[tile stamps] n=%llu", (unsigned long long)c->n);
+        if (h[47])
+            fprintf(stderr, "[P5 cells] per colour pass: %.1f one-lane cells, %.1f lane-group cells, %.2f whole-wave cells of %.1f members (largest %.1f);"
+                    " a wave spends %.0f cycles in them\n", (double)h[44] / h[47], (double)h[45] / h[47], (double)h[46] / h[47],
+                    h[46] ? (double)h[49] / h[46] : 0.0, (double)h[50] / h[47], (double)h[48] / (double)(h[40] + h[41] + h[42]));
         double all = 0;
         for (int i = 0; i < 14; ++i) all += (double)h[i];
         for (int i = 0; i < 14; ++i)

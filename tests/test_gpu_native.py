@@ -296,6 +296,25 @@ def test_native_crushed_cells_are_exact(gpe, oracle):
     st.close(); sim.close()
 
 
+@pytest.mark.parametrize("n", [2400, 3000, 4200])
+def test_native_cells_of_nine_to_sixteen_members_are_exact(gpe, oracle, n):
+    """A compressed region at 2.2 .. 3.9 particles per cell: with their phantom memberships most collision cells hold
+    9..16 members -- the sub-tile windows resolve those by the sixteen lanes of a DPP row, four cells per wave
+    (resolve_row), beside lane groups (4..8) and whole-wave cells (17 and more); 16x16 windows at the lowest density,
+    8x8 windows above.  Same bits as the oracle."""
+    world = (33.0, 33.0)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=77 + n)
+    st = _native(gpe, pos, rad, world, flags=gpe._lib.FLAG_NATIVE_FORCE)
+    sim = oracle.Sim(pos, rad, oracle.default_params(world[0], world[1], 0.5))
+    for s in range(4):
+        st.update(1 / 60, resort=(s == 0)); sim.step(1 / 60, resort=(s == 0))
+        _assert_positions(st.positions(), sim.pos, "cells of 9..16 members, step %d" % s)
+    st.ctx.sync()
+    info = st.ctx.pipeline_info()
+    assert info["native_steps"] == 4 and info["overflow_tiles"] > 0
+    st.close(); sim.close()
+
+
 def _threads():
     import os
     try:
