@@ -2072,7 +2072,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                         const int lc = S.wlist[k * L::WC + i];
                         const uint32_t m = S.cell_get(lc + 1) - S.cell_get(lc);
                         members += m; largest = max(largest, m);
+                        atomicAdd(&A.stamps[52 + (m <= 16u ? 0 : m <= 32u ? 1 : m <= 64u ? 2 : 3)], 1ull);
                     }
+                    atomicAdd(&A.stamps[51], (unsigned long long)min(S.lcnt[12 + k], (uint32_t)L::WC));
                     atomicAdd(&A.stamps[49], (unsigned long long)members);
                     atomicAdd(&A.stamps[50], (unsigned long long)largest);
                 }
@@ -3639,8 +3641,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         fprintf(stderr, "[tile stamps] n=%llu", (unsigned long long)c->n);
         if (h[47])
             fprintf(stderr, "[P5 cells] per colour pass: %.1f one-lane cells, %.1f lane-group cells, %.2f whole-wave cells of %.1f members (largest %.1f);"
-                    " a wave spends %.0f cycles in them\n", (double)h[44] / h[47], (double)h[45] / h[47], (double)h[46] / h[47],
-                    h[46] ? (double)h[49] / h[46] : 0.0, (double)h[50] / h[47], (double)h[48] / (double)(h[40] + h[41] + h[42]));
+                    " a wave spends %.0f cycles in them and the rows; %.2f row cells; whole-wave cells by members <=16 / <=32 / <=64 / more: %.2f %.2f %.2f %.2f\n",
+                    (double)h[44] / h[47], (double)h[45] / h[47], (double)h[46] / h[47],
+                    h[46] ? (double)h[49] / h[46] : 0.0, (double)h[50] / h[47], (double)h[48] / (double)(h[40] + h[41] + h[42]),
+                    (double)h[51] / h[47], (double)h[52] / h[47], (double)h[53] / h[47], (double)h[54] / h[47], (double)h[55] / h[47]);
         double all = 0;
         for (int i = 0; i < 14; ++i) all += (double)h[i];
         for (int i = 0; i < 14; ++i)
