@@ -1338,42 +1338,56 @@ __device__ __forceinline__ void resolve_wave(L &S, const uint32_t b, const uint3
 // when they leave the last owner's lane: 64 + |J| - 1 steps.  Row-major block order gives every pair its two
 // predecessors, so every particle sees its updates in the reference's order: same bits, ~n^2/64 steps instead
 // of n (n - 1) / 2 pairs in one lane.
-constexpr uint32_t kWaveCellMax = 256;
+// (Up to 1024 members since round 4: by step 2000 of the 100 M gravity-on scene the two floor corners hold cells of 330,
+// by step 2450 of 600 members; beyond this limit a cell falls to ONE lane -- 180 k pairs one after the other, each with
+// the spill window's global round trips in its chain: one such tile took 107 M cycles, 2.7 x the over-capacity launch's
+// whole balanced duration; profiles/r04/tile_cycles_tail.txt.)
+constexpr uint32_t kWaveCellMax = 1024;
 template <class L>
 __device__ __forceinline__ void resolve_wave_blocked(L &S, const uint32_t b, const uint32_t n, const float stiffness)
 {
     const int a = lane_id();
     constexpr int K = (int)kWaveCellMax / 64;
-    // members into ascending object index: rank count over the whole cell, four members per lane
+    const uint32_t chunks = (n + 63u) / 64u;
+    // members into ascending object index: rank count over the whole cell, up to sixteen members per lane; the rank
+    // rides in the slot word's upper bits (slots stay below 2^22: P4 sends no cell of a larger window here)
     {
-        uint32_t slot[K], id[K], rank[K];
+        constexpr uint32_t kRankOne = 1u << 22;
+        uint32_t pk[K], id[K];
+        // (branch-free: a lane without a member in chunk k re-reads the cell's first member and discards it -- behind
+        // per-chunk branches hipcc kept sixteen copies of the two arrays alive and spilled them)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t m = (uint32_t)a + 64u * k;
-            slot[k] = m < n ? (uint32_t)S.mem[b + m] : 0u;
+            pk[k] = (uint32_t)S.mem[b + (m < n ? m : 0u)];
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t m = (uint32_t)a + 64u * k;
-            id[k] = m < n ? S.id[slot[k]] : 0xFFFFFFFFu;
-            rank[k] = 0;
+            const uint32_t v = S.id[pk[k]];
+            id[k] = m < n ? v : 0xFFFFFFFFu;
         }
+#pragma unroll 1
+        for (uint32_t kk = 0; kk < chunks; ++kk) {
+            // (one copy of the loops: the chunk's ids by a chain of selects on the wave-uniform kk, not sixteen unrolled
+            // bodies -- that form doubled the kernel's code and left its register arrays in scratch)
+            uint32_t cur = id[0];
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-            const int lim = (int)min(64u, n > 64u * kk ? n - 64u * kk : 0u);       // wave-uniform
+            for (int k = 1; k < K; ++k) cur = kk == (uint32_t)k ? id[k] : cur;
+            const int lim = (int)min(64u, n - 64u * kk);                  // wave-uniform
+#pragma unroll 1
             for (int i = 0; i < lim; ++i) {
-                const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)id[kk], i);
+                const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)cur, i);
 #pragma unroll
-                for (int k = 0; k < K; ++k) rank[k] += other < id[k] ? 1u : 0u;
+                for (int k = 0; k < K; ++k) pk[k] += other < id[k] ? kRankOne : 0u;
             }
         }
         wave_lds_order();                                              // every read of mem above precedes the writes
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            if ((uint32_t)a + 64u * k < n) S.mem[b + rank[k]] = slot[k];
+            if ((uint32_t)a + 64u * k < n) S.mem[b + (pk[k] >> 22)] = pk[k] & (kRankOne - 1u);
         wave_lds_order();
     }
-    const uint32_t chunks = (n + 63u) / 64u;
     for (uint32_t I = 0; I < chunks; ++I) {
         const uint32_t bI = b + 64u * I, cI = min(64u, n - 64u * I);
         resolve_wave(S, bI, cI, stiffness);                            // pairs inside chunk I (it re-ranks: already sorted)
@@ -1391,23 +1405,29 @@ __device__ __forceinline__ void resolve_wave_blocked(L &S, const uint32_t b, con
         const bool first = a == 0;
         for (uint32_t J = I + 1; J < chunks; ++J) {
             const uint32_t bJ = b + 64u * J, cJ = min(64u, n - 64u * J);
+            // the visitors of chunk J: fetched by the 64 lanes at once, handed to lane 0 one per step with v_readlane
+            // (a spill window keeps its arrays in global memory: fetched by lane 0 one step ahead, as until round 4,
+            // every step waited for two dependent global round trips)
+            int vs = 0;
+            f32x2 vp = {0.f, 0.f};
+            float vr = 1.f;
+            if ((uint32_t)a < cJ) { vs = (int)S.mem[bJ + a]; vp = (f32x2){S.px[vs], S.py[vs]}; vr = S.rad[vs]; }
             f32x2 qp = {0.f, 0.f};
             float qr = 1.f;
             int qb = -1, qs = 0;
-            // lane 0 fetches the visitor one step ahead
-            f32x2 np = {0.f, 0.f};
-            float nr = 1.f;
-            int ns = 0;
-            if (first) { ns = (int)S.mem[bJ]; np = (f32x2){S.px[ns], S.py[ns]}; nr = S.rad[ns]; }
             const int steps = (int)(cI + cJ) - 1;
             for (int t = 0; t < steps; ++t) {
                 f32x2 ip = wave_from_lane_below(qp);
                 float ir = wave_from_lane_below(qr);
                 int ib = wave_from_lane_below(qb), is = wave_from_lane_below(qs);
+                const int tv = t & 63;                                 // (t >= cJ: no visitor enters, the values are unused)
+                const f32x2 np = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(vp.x), tv)),
+                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vp.y), tv))};
+                const float nr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vr), tv));
+                const int ns = __builtin_amdgcn_readlane(vs, tv);
                 if (first) {
                     ip = np; ir = nr; is = ns;
                     ib = t < (int)cJ ? t : -1;
-                    if (t + 1 < (int)cJ) { ns = (int)S.mem[bJ + t + 1]; np = (f32x2){S.px[ns], S.py[ns]}; nr = S.rad[ns]; }
                 }
                 const uint64_t pairing_m = has_m & ballot64(ib >= 0);
                 (void)pair_response(pairing_m, p1, ip, r1, ir, plain, stiffness);
@@ -1918,7 +1938,9 @@ __device__ __forceinline__ bool process_tile(L &S, const CollideArgs &A, const i
                 // cells of 9..64 members go to a whole wave each (resolve_wave), as far as the colour's list takes
                 // (65..256 members: blocked, in the sub-tile and spill windows only; a main tile that meets such a
                 // cell hands itself over to them)
-                constexpr uint32_t kWaveMax = (T >= 32) ? 64u : kWaveCellMax;
+                // (the blocked form packs a member's rank above its 22-bit slot: a spill window of 4 M particles and more
+                // -- the whole system in 24 x 24 cells -- leaves its piles to one lane)
+                const uint32_t kWaveMax = (T >= 32 || PS >= (1u << 22)) ? 64u : kWaveCellMax;
                 const uint64_t big_m = act_m & ballot64(cnt[c] > kGroupLanes);
                 uint64_t wave_m = big_m & ballot64(cnt[c] <= kWaveMax);
                 if (big_m != 0) {                                      // (scalar: no such cell in most rounds)

@@ -42,4 +42,10 @@ for m in marks:
     d = cyc[outcome == 0]
     if d.size:
         print("   done tiles: cycles percentiles 10/50/90/99/max = %s" % " / ".join("%d" % v for v in np.percentile(d, [10, 50, 90, 99, 100])))
+    q = qcyc[qcyc > 0]
+    if q.size:
+        # the over-capacity launch ends with its slowest workgroup: the tail of the tiles' quarter cycles
+        top = np.sort(q)[::-1]
+        print("   over-capacity tiles: quarter cycles percentiles 50/90/99/99.9/max = %s; the 10 slowest: %s; all of them / 768 workgroups = %.3g cycles" %
+              (" / ".join("%d" % v for v in np.percentile(q, [50, 90, 99, 99.9, 100])), " ".join("%.3g" % v for v in top[:10]), q.sum() / 768.0))
 print(st.ctx.pipeline_info())

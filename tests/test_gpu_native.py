@@ -276,15 +276,17 @@ def test_native_mouse_blob_hands_over_without_error(gpe):
     a.close(); b.close()
 
 
-def test_native_crushed_cells_are_exact(gpe, oracle):
-    """Cells of ~100 members (a crushed pile): whole-wave resolution (9..64 members) and its blocked form (65..256)
-    in the sub-tile and spill windows, kept on the native kernels by GPE_FLAG_NATIVE_FORCE -- same bits as the oracle."""
+@pytest.mark.parametrize("sizes", [(90, 150, 240), (300, 640, 1000), (30, 1100, 257)])
+def test_native_crushed_cells_are_exact(gpe, oracle, sizes):
+    """Cells of ~100 members (a crushed pile): whole-wave resolution (9..64 members) and its blocked form (65..1024:
+    the floor corners of the 100 M gravity-on scene hold 600 by step 2450) in the sub-tile and spill windows, one lane
+    beyond that; kept on the native kernels by GPE_FLAG_NATIVE_FORCE -- same bits as the oracle."""
     rng = np.random.default_rng(21)
     world = (40.0, 40.0)
-    # a sparse background plus three blobs of 90, 150 and 240 particles inside one cell each
+    # a sparse background plus three blobs of particles inside one cell each
     bg = (rng.random((1500, 2), dtype=np.float32) * np.float32(40.0)).astype(np.float32)
     blobs = [np.array(c, np.float32) + rng.random((k, 2), dtype=np.float32) * np.float32(0.9)
-             for c, k in (((11.1, 11.1), 90), ((22.1, 16.6), 150), ((30.9, 30.9), 240))]
+             for c, k in zip(((11.1, 11.1), (22.1, 16.6), (30.9, 30.9)), sizes)]
     pos = np.concatenate([bg] + blobs).astype(np.float32)
     rad = np.full(len(pos), 0.5, np.float32)
     st = _native(gpe, pos, rad, world, flags=gpe._lib.FLAG_NATIVE_FORCE)
