@@ -608,7 +608,7 @@ def test_dense_patch_on_the_border_between_two_ranks(gpe, overlap):
     """A patch of ~3 x 3 tiles at 1.9 x the benchmark density and a small blob far denser than that, both astride the cut
     between two ranks: the order-key tiles there keep more particles than the direct-slot form stages (880), so they are
     handed on -- to the half-tile launch (k_collide_halves<ORD>, which packs for the neighbour like any border tile) and,
-    the blob, to the 16 x 16 / 8 x 8 windows; with the exchange beside the step (overlap) the border tiles are redone on
+    the blob and a one-cell pile of 700, to the 16 x 16 / 8 x 8 / spill windows; with the exchange beside the step (overlap) the border tiles are redone on
     the spot by k_collide_border instead.  Bit-identical to the single-context run; gravity drags the patch across the cut."""
     lg = importlib.import_module("gpu-physics-engine_amd.local_group")
     n, world, g = 60_000, (500.0, 380.0), (12.0, -6.0)
@@ -618,7 +618,10 @@ def test_dense_patch_on_the_border_between_two_ranks(gpe, overlap):
     extra = int(0.9 * 0.3131 * float(side) ** 2)
     patch = (np.array([250.0 - float(side) / 2, 120.0], np.float32) + rng.random((extra, 2), dtype=np.float32) * side).astype(np.float32)
     blob = (np.array([243.0, 300.0], np.float32) + rng.random((1200, 2), dtype=np.float32) * np.float32(14.0)).astype(np.float32)
-    pos = np.concatenate([pos, patch, blob]).astype(np.float32)
+    # ... and 700 particles pressed into one cell next to the cut: a cell for the blocked whole-wave walk (65..1024 members)
+    # of an order-key spill window, its neighbours (phantom members) for rows and whole waves
+    pile = (np.array([249.7, 200.2], np.float32) + rng.random((700, 2), dtype=np.float32) * np.float32(0.9)).astype(np.float32)
+    pos = np.concatenate([pos, patch, blob, pile]).astype(np.float32)
     rad = np.full(len(pos), 0.5, np.float32)
     steps, dt, every = 20, 1 / 60, 12
     run = lg.LocalShardedRun(pos, rad, world, 2, gravity=g, grid=(2, 1), flags=gpe._lib.FLAG_SHARD_OVERLAP if overlap else 0)
