@@ -283,6 +283,8 @@ constexpr int kStatProbe = 2;                  // window population measured by 
 constexpr int kStatOverflow = 3;               // 32x32 tiles over capacity in the last native step
 constexpr int kStatSubTiles = 4, kStatSpills = 5;   // quarters redone as 8x8 tiles / 8x8 tiles through the arena (diagnostics)
 constexpr int kStatSorts = 6;                  // running count of steps whose radix passes ran (tile_ctl[kCtlSorts]), lagged
+constexpr int kStatOverflowNew = 7;            // ... of kStatOverflow, the tiles the dense launch handed on itself (the others were known: hinted)
+constexpr int kStatHalvesOver = 8;             // halves handed on to the over-capacity launch in the last native step
 constexpr int kNativeCtlSorts = 14;         // tile_ctl word: running count of steps whose radix passes ran (k_native.hip kCtlSorts)
 constexpr int kNativeCtlSortsSeen = 38;     // its copy in the line the tiles only read (k_native.hip kCtlSortsSeen)
 // Native (N-key sort + LDS cell windows) pipeline state
@@ -330,6 +332,9 @@ struct NativeState {
     uint32_t hist_watch_steps = 0, hist_watch_sorts = 0;
     uint32_t quiet_steps = 0;        // native steps since the tiles last reported an over-capacity 32x32 tile (lagged)
     uint32_t step_seq = 0;           // native_prepare_step calls: its parity selects the per-step control words
+    uint32_t collide_seq = 0;        // native_collide calls: numbers the dense launches for the tile hints (k_native.hip kCtlHints)
+    uint32_t hint_quiet = 0xFFFFFFFFu; // native steps since a tile last ran over, hinted ones included (lagged): the dense launch's front workgroups
+    uint32_t dense_quiet = 0;        // native steps since list 1 or list 2 last had an entry (lagged): the over-capacity launch's grid
     const uint32_t *fresh_word = nullptr;   // tile_ctl word the tiles of the current step read (did the passes run?)
     uint32_t reason = GPE_REASON_NO_PARTICLES;   // why the native kernels do not run (GPE_REASON_*), NONE when they do
     uint64_t native_steps = 0, compat_steps = 0;

@@ -90,6 +90,20 @@ constexpr int kCtlOverflowTicket = 4;          // next work item of the over-cap
 constexpr int kCtlSubTiles = 5;                // 16x16 quarters redone as four 8x8 tiles this step
 constexpr int kCtlSpills = 6;                  // 8x8 tiles staged in the global spill arena this step
 constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every step
+// HINTS: a tile the direct-slot dense launch hands on is, as a rule, over capacity on the next step too (a clump lives for
+// hundreds of steps).  It registers itself for the next collide launch -- hints[next parity][k], k from tile_ctl[kCtlHints
+// + next parity], and that launch's number in the fourth word of its roster header -- and there the FIRST kHintMax * 2
+// workgroups of the dense launch redo it as two 32x16 halves while the others resolve their tiles: nothing waits behind
+// the dense launch for it (the half-tile launch there cost the 1 M step ~20 us from step ~1000 of the benchmark run on).
+// The tile's own workgroup sees the number in the header it loads anyway and returns; the half workgroup registers the
+// tile again unless the table was re-sorted (the tile then runs over once more and registers itself).  Launches are
+// numbered by native_collide itself (not by step: a host may collide twice on one grid); the list a launch has used is
+// cleared behind it by its over-capacity launch.  Exact whatever the lists hold: a tile is skipped by its own workgroup
+// iff its header carries this launch's number or the next one's (registered again already, by a front workgroup -- or by
+// itself, which is past the test), and a front workgroup takes a listed tile iff the header carries one of the two.
+constexpr int kCtlHints = 11;                  // [launch parity] tiles registered for the launch of that parity
+constexpr int kCtlHintsSeen = 13;              // hinted tiles of the last launch (statistics)
+constexpr uint32_t kHintMax = 32;
 constexpr int kCtlError = 8;                   // sticky
 // Two words each, indexed by the parity of the step (native_prepare_step counts them): a step's hash kernel clears
 // the NEXT step's word while its own is being set, so no workgroup of a launch races with another's reset.
@@ -299,7 +313,13 @@ __global__ __launch_bounds__(kHashBlock, 8) void k_native_hash(const float2 *__r
         if (host_stat) {                                               // last step's statistics (kStat*), lagged
             if (threadIdx.x == kCtlWindowMax) host_stat[kStatWindowMax] = tile_ctl[kCtlWindowMax];
             if (threadIdx.x == kCtlArena) host_stat[kStatArena] = tile_ctl[kCtlArena];
-            if (threadIdx.x == kCtlOverflow1) host_stat[kStatOverflow] = tile_ctl[kCtlOverflow1];
+            if (threadIdx.x == kCtlOverflow1) {
+                // (+ the hinted tiles of the last launch)
+                const uint32_t fresh_over = tile_ctl[kCtlOverflow1];
+                host_stat[kStatOverflow] = fresh_over + tile_ctl[kCtlHintsSeen];
+                host_stat[kStatOverflowNew] = fresh_over;
+            }
+            if (threadIdx.x == kCtlOverflow2) host_stat[kStatHalvesOver] = tile_ctl[kCtlOverflow2];
             if (threadIdx.x == kCtlSubTiles) host_stat[kStatSubTiles] = tile_ctl[kCtlSubTiles];
             if (threadIdx.x == kCtlSpills) host_stat[kStatSpills] = tile_ctl[kCtlSpills];
             if (threadIdx.x == 7) host_stat[kStatSorts] = tile_ctl[kCtlSorts];
@@ -640,7 +660,11 @@ struct CollideArgs {
     // so 1.6 x the particles per cell fit, at the dense launch's cost per particle); the halves it cannot take either
     // are listed in overflow2 (packed ty16 << 16 | tx32) and the over-capacity launch works through that list.
     uint32_t *overflow2;
-    uint32_t quarters_of_halves; // the over-capacity launch takes its quarters from overflow2 (two per half), not overflow1
+    uint32_t quarters_of_halves; // list 1 was taken by the half-tile launch: the over-capacity launch only takes overflow2 (two quarters per half)
+    // hints (kCtlHints): hints[parity * kHintMax + k] = ty << 16 | tx; front_wgs == 0: no hints this launch
+    uint32_t *hints;
+    uint32_t step_stamp, front_wgs, hint_parity;
+    uint32_t hints_on;           // tiles that run over register themselves (front_wgs != 0: ... and this launch redoes the registered ones)
     // spill arena (global memory) for the particle arrays of such tiles
     float *arena_px, *arena_py, *arena_rad;
     uint32_t *arena_id, *arena_hm, *arena_mem;   // arena_mem holds 4 entries per particle
@@ -2368,7 +2392,7 @@ struct TileDirect {
     uint32_t misc[6];          // [0] looked up, [2] hand the tile on, [3] kept, [4] side-list entries
 };
 
-template <bool ORD, class L>
+template <bool ORD, class L, bool HINTS = false>
 __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, const int tx, const int ty)
 {
     constexpr int TX = L::TX, TY = L::TY, NT = L::NT, NW = L::NW;
@@ -2425,6 +2449,11 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         if (A.gho_count == nullptr || __builtin_amdgcn_readfirstlane((int)gsort_word) != 0) return false;
     }
     const uint32_t stamp_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorts_word) + 1u;
+    if constexpr (kRoster && HINTS) {
+        // a hinted tile (kCtlHints): two of the launch's first workgroups redo it as halves
+        const uint32_t hinted_for = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.w);
+        if (rosters && A.front_wgs != 0u && (hinted_for == A.step_stamp || hinted_for == A.step_stamp + 1u)) return true;
+    }
     // (scalar) the roster is of the table in use: no lookup
     const bool listed = rosters && stale && (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y) == stamp_now;
     const bool record = rosters && !listed && A.roster_write != 0u;
@@ -2495,7 +2524,7 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     if (record && tid == 0) {
         // the header of the roster the gather below writes (an empty lookup is a valid, empty roster)
         const uint32_t count = P > (uint32_t)L::RAWCAP ? 0xFFFFFFFFu : P;
-        A.roster_hdr[pt] = make_uint4(count, stamp_now, S.misc[5], 0u);
+        A.roster_hdr[pt] = make_uint4(count, stamp_now, S.misc[5], 0u);   // (w: no hint)
     }
     {
         // nothing of its own to write?  (see process_tile: own blocks with the table of this step; the whole lookup
@@ -2924,16 +2953,74 @@ static uint32_t dense_launch_grid(uint32_t tiles_x, uint32_t tiles_y, uint32_t b
     return (uint32_t)(((bands + 7u) / 8u) * band_tiles * 8u);
 }
 
-template <int TX, int CAP, bool ORD, int NT>
+// (three workgroups per CU: 80 VGPRs and 53 KB of LDS each -- room for 2000 particles, what a half of a tile at ~6 x the
+// benchmark density keeps; an order-key window pays 4 more bytes per particle)
+#ifndef GPE_CAP_HALF
+#define GPE_CAP_HALF 2000
+#endif
+#ifndef GPE_CAP_HALF_ORD
+#define GPE_CAP_HALF_ORD 1680
+#endif
+#ifndef GPE_CAP_HALF_FRONT
+#define GPE_CAP_HALF_FRONT 1392                 // a half redone by the dense launch's front workgroups (kCtlHints): the tile's LDS
+#endif
+// Registers a tile that ran over for the front workgroups of the next step's dense launch (kCtlHints).
+__device__ __forceinline__ void hint_tile(const CollideArgs &A, const int tx, const int ty)
+{
+    if (A.hints_on == 0u || !A.tb.holds(tx, ty)) return;
+    const uint32_t next = A.hint_parity ^ 1u;
+    const uint32_t k = atomicAdd(&A.tile_ctl[kCtlHints + next], 1u);
+    if (k >= kHintMax) return;
+    A.hints[next * kHintMax + k] = ((uint32_t)ty << 16) | (uint32_t)tx;
+    A.roster_hdr[A.tb.index(tx, ty)].w = A.step_stamp + 1u;
+}
+
+// HINTS: the launch carries front workgroups for the registered tiles (kCtlHints) -- a kernel of its own, launched only
+// while such tiles exist: the plain kernel is 3 % faster without the code (48.0 against 49.5 us at 1 M).
+template <int TX, int CAP, bool ORD, int NT, bool HINTS = false>
 __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
 {
+    static_assert(!(HINTS && ORD), "hints: plain runs only");
+    // (The half-tile form of the hinted tiles lives in the tile's own LDS: 40 928 bytes, four workgroups per CU, hold a
+    // half of 1392 particles -- 59 % of a tile's window at 1.5 x its capacity; the half-tile launch's 2000 would make it
+    // 51 KB and three per CU: 54.2 instead of 47.8 us at 1 M, profiles/r04/ab_hints_bisect.txt.)
+    struct NoHalf { char unused; };
+    using Half = typename std::conditional<HINTS, TileDirect<32, 16, GPE_CAP_HALF_FRONT, false, 512>, NoHalf>::type;
     __shared__ TileDirect<TX, 32, CAP, ORD, NT> S;
+    static_assert(sizeof(Half) <= sizeof(S) && alignof(Half) <= alignof(TileDirect<TX, 32, CAP, ORD, NT>), "the half form fits the tile's LDS");
+    uint32_t wg = blockIdx.x;
+    if constexpr (HINTS) {
+        if (wg < A.front_wgs) {
+            // half (wg & 1) of hinted tile wg >> 1
+            const uint32_t count = min(A.tile_ctl[kCtlHints + A.hint_parity], kHintMax);
+            if ((wg >> 1) >= count) return;
+            const uint32_t tile = A.hints[A.hint_parity * kHintMax + (wg >> 1)];
+            const int htx = (int)(tile & 0xFFFFu), hty = (int)(tile >> 16);
+            if (!A.tb.holds(htx, hty)) return;
+            const uint32_t hinted_for = A.roster_hdr[A.tb.index(htx, hty)].w;   // (not registered for this launch: its own workgroup takes it)
+            if (hinted_for != A.step_stamp && hinted_for != A.step_stamp + 1u) return;
+            const bool fresh = *A.fresh != 0u;
+            const int hy = hty * 2 + (int)(wg & 1u);
+            const bool done = process_tile_direct<false>(*reinterpret_cast<Half *>(&S), A, htx, hy);
+            if (threadIdx.x == 0) {
+                if (!done) {
+                    const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow2], 1u);
+                    if (slot < 2u * A.overflow1_cap) A.overflow2[slot] = ((uint32_t)hy << 16) | (uint32_t)htx;
+                    else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
+                }
+                // again on the next step -- unless the table was re-sorted: the tile then tries itself first
+                if ((wg & 1u) == 0u && !fresh) hint_tile(A, htx, hty);
+            }
+            return;
+        }
+        wg -= A.front_wgs;                                             // (a multiple of 8: the XCD of a tile stays)
+    }
     int tx, ty;
-    if (!dense_launch_tile(A, blockIdx.x, &tx, &ty)) return;
+    if (!dense_launch_tile(A, wg, &tx, &ty)) return;
 #ifdef GPE_TILE_CYCLES
     const long long tc0 = clock64();
 #endif
-    const bool done = process_tile_direct<ORD>(S, A, tx, ty);
+    const bool done = process_tile_direct<ORD, TileDirect<TX, 32, CAP, ORD, NT>, HINTS>(S, A, tx, ty);
 #ifdef GPE_TILE_CYCLES
     if (g_tile_cycles && threadIdx.x == 0 && A.tb.holds(tx, ty)) {
         uint4 *e = &g_tile_cycles[A.tb.index(tx, ty)];
@@ -2941,6 +3028,7 @@ __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
     }
 #endif
     if (!done) {
+        // (the launch that takes the tile off list 1 -- half tiles or over-capacity windows -- registers it: kCtlHints)
         if (threadIdx.x == 0) {
             const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow1], 1u);
             if (slot < A.overflow1_cap) A.overflow1[slot] = ((uint32_t)ty << 16) | (uint32_t)tx;
@@ -2997,14 +3085,6 @@ __global__ __launch_bounds__(kNatThreads, 2048 / kNatThreads * 2) void k_collide
     }
 }
 
-// (three workgroups per CU: 80 VGPRs and 53 KB of LDS each -- room for 2000 particles, what a half of a tile at ~6 x the
-// benchmark density keeps; an order-key window pays 4 more bytes per particle)
-#ifndef GPE_CAP_HALF
-#define GPE_CAP_HALF 2000
-#endif
-#ifndef GPE_CAP_HALF_ORD
-#define GPE_CAP_HALF_ORD 1680
-#endif
 // The 32x32 tiles the dense launch handed on, each redone as two 32x16 halves in the direct-slot form (CollideArgs::
 // overflow2): a ticketed grid like the over-capacity launch's, only launched while the host's lagged statistic reports
 // such tiles.  A half that does not fit either is listed for the over-capacity launch's 16x16 / 8x8 windows.
@@ -3027,6 +3107,7 @@ __global__ __launch_bounds__(512, 6) void k_collide_halves(CollideArgs A)
         if (i >= work) break;
         const uint32_t parent = A.overflow1[i >> 1];
         const int tx = (int)(parent & 0xFFFFu), ty = (int)((parent >> 16) * 2u + (i & 1u));
+        if ((i & 1u) == 0u && threadIdx.x == 0) hint_tile(A, tx, (int)(parent >> 16));   // (for the next dense launch: kCtlHints)
         const bool done = process_tile_direct<ORD>(S, A, tx, ty);
         __syncthreads();
         if (!done && threadIdx.x == 0) {
@@ -3047,11 +3128,17 @@ __global__ __launch_bounds__(kNatThreads, GPE_OVF_WAVES) void k_collide_overflow
 {
     __shared__ OverflowLds<ORD> u;
     __shared__ uint32_t s_item;
-    // work items: the four quarters of every tile of list 1, or the two of every half of list 2 (CollideArgs)
-    const bool halves = A.quarters_of_halves != 0u;
-    uint32_t count = A.tile_ctl[halves ? kCtlOverflow2 : kCtlOverflow1];
-    if (count > (halves ? 2u : 1u) * A.overflow1_cap) count = (halves ? 2u : 1u) * A.overflow1_cap;
-    const uint32_t work = count * (halves ? 2u : 4u);
+    // work items: the four quarters of every tile of list 1 (unless the half-tile launch took that list), then the two
+    // of every half of list 2 (CollideArgs)
+    const uint32_t count1 = A.quarters_of_halves != 0u ? 0u : min(A.tile_ctl[kCtlOverflow1], A.overflow1_cap);
+    const uint32_t count2 = min(A.tile_ctl[kCtlOverflow2], 2u * A.overflow1_cap);
+    const uint32_t work1 = count1 * 4u, work = work1 + count2 * 2u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the hints this collide launch has used: counted for the statistics, the list free for the launch after the next
+        const uint32_t used = min(A.tile_ctl[kCtlHints + A.hint_parity], kHintMax);
+        A.tile_ctl[kCtlHintsSeen] = A.front_wgs != 0u ? used : 0u;
+        A.tile_ctl[kCtlHints + A.hint_parity] = 0u;
+    }
     if (work == 0) return;
     // Work items are taken from a ticket counter: their durations differ by orders of magnitude (in a compressed scene
     // the lower quarters of a tile hold several times the particles of the upper ones), and a fixed stride of 1024
@@ -3064,8 +3151,11 @@ __global__ __launch_bounds__(kNatThreads, GPE_OVF_WAVES) void k_collide_overflow
         if (i >= work) break;
         // the quarter, in 16-cell units, and its 32x32 tile
         uint32_t qx, qy;
-        if (halves) { const uint32_t h = A.overflow2[i >> 1]; qx = (h & 0xFFFFu) * 2u + (i & 1u); qy = h >> 16; }
-        else { const uint32_t parent = A.overflow1[i >> 2]; qx = (parent & 0xFFFFu) * 2u + (i & 1u); qy = (parent >> 16) * 2u + ((i >> 1) & 1u); }
+        if (i >= work1) { const uint32_t h = A.overflow2[(i - work1) >> 1]; qx = (h & 0xFFFFu) * 2u + (i & 1u); qy = h >> 16; }
+        else {
+            const uint32_t parent = A.overflow1[i >> 2]; qx = (parent & 0xFFFFu) * 2u + (i & 1u); qy = (parent >> 16) * 2u + ((i >> 1) & 1u);
+            if ((i & 3u) == 0u && threadIdx.x == 0) hint_tile(A, (int)(parent & 0xFFFFu), (int)(parent >> 16));   // (kCtlHints)
+        }
 #ifdef GPE_TILE_CYCLES
         const long long tq0 = clock64();
 #endif
@@ -3438,7 +3528,7 @@ gpe_status native_configure(gpe_ctx *c)
     if (N.overflow_cap < tiles) {
         if (N.overflow1) GPE_HIP(c, hipFree(N.overflow1));
         N.overflow1 = nullptr; N.overflow_cap = 0;
-        GPE_HIP(c, hipMalloc((void **)&N.overflow1, (3 * tiles + 32) * sizeof(uint32_t)));   // (the tiles, then their halves: CollideArgs::overflow2)
+        GPE_HIP(c, hipMalloc((void **)&N.overflow1, (3 * tiles + 32 + 2 * kHintMax) * sizeof(uint32_t)));   // (the tiles, then their halves: CollideArgs::overflow2, then the hints)
         N.overflow_cap = tiles;
     }
     {
@@ -3625,6 +3715,12 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
     A.overflow1_cap = (uint32_t)N.overflow_cap;
     A.overflow2 = N.overflow1 + N.overflow_cap + 16;
     A.quarters_of_halves = 0u;
+    A.hints = N.overflow1 + 3 * N.overflow_cap + 32;                   // 2 x kHintMax words behind the two lists
+    A.hint_parity = N.collide_seq & 1u;
+    A.step_stamp = N.collide_seq + 16u;                                // (never the 0 of a cleared roster header)
+    ++N.collide_seq;
+    A.front_wgs = 0u;
+    A.hints_on = 0u;
     {
         // arena layout: px | py | rad | id | hm | mem (4 per slot) | sblk
         float *f = (float *)N.arena;
@@ -3763,7 +3859,19 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
             if (!split)
                 hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         } else {
-            hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
+            // Hinted tiles (kCtlHints): the launch's first workgroups redo them as halves.  With rosters only (the hint
+            // travels in the roster header the tile loads anyway), and only while tiles have run over lately (lagged
+            // statistic, hinted tiles included): the kernel that carries the front workgroups is 3 % slower than the
+            // plain one.  Until it is launched a registered tile simply tries itself again.
+            if (A.roster_hdr != nullptr && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0) {
+                A.hints_on = 1u;
+                if (N.host_stat[kStatOverflow] != 0) N.hint_quiet = 0; else if (N.hint_quiet < 0xFFFFFFFFu) ++N.hint_quiet;
+                if (N.hint_quiet < 32u) A.front_wgs = 2u * kHintMax;
+            }
+            if (A.front_wgs)
+                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512, true>), dim3(grid + A.front_wgs), dim3(512), 0, c->stream, A);
+            else
+                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512>), dim3(grid), dim3(512), 0, c->stream, A);
         }
         GPE_HIP(c, hipGetLastError());
     }
@@ -3776,8 +3884,12 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // over-capacity tile for a while (the statistic lags by the steps in flight) the grid is 128 workgroups; the
         // first reported tile brings the full grid back.  A surprise only makes that one step's launch slower.
         Scope s(c, "native/collide-dense-regions");
-        if (N.host_stat && N.host_stat[kStatOverflow] != 0) N.quiet_steps = 0;
+        // (quiet_steps: since the dense launch last handed a tile on ITSELF -- hinted tiles do not count, they never reach
+        // list 1; dense_quiet: since anything reached list 1 or list 2)
+        if (N.host_stat && N.host_stat[A.front_wgs ? kStatOverflowNew : kStatOverflow] != 0) N.quiet_steps = 0;
         else if (N.quiet_steps < 0xFFFFFFFFu) ++N.quiet_steps;
+        if (N.host_stat && (N.host_stat[kStatOverflowNew] != 0 || N.host_stat[kStatHalvesOver] != 0 || (!A.front_wgs && N.host_stat[kStatOverflow] != 0))) N.dense_quiet = 0;
+        else if (N.dense_quiet < 0xFFFFFFFFu) ++N.dense_quiet;
         // The half-tile launch: while the direct-slot launch has handed tiles on lately (lagged; either way is exact --
         // without it the over-capacity launch takes the tiles of list 1).  Not behind counting-sort tiles: what does not
         // fit their 1192 particles is dense enough for the windows.
@@ -3786,7 +3898,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // with halves behind it up to 50 % of the tiles was measured: step 2000 of the 100 M soak 35.5 instead of 31.0 ms.)
         if (direct_form && N.quiet_steps < 32u && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0) {
             A.quarters_of_halves = 1u;
-            const uint32_t hgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, 2ull * N.host_stat[kStatOverflow] + 32));
+            const uint32_t hgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, 2ull * N.host_stat[A.front_wgs ? kStatOverflowNew : kStatOverflow] + 32));
             if (A.order_keys)
                 hipLaunchKernelGGL(k_collide_halves<true>, dim3(hgrid), dim3(512), 0, c->stream, A);
             else
@@ -3795,7 +3907,7 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         }
         // (Only where the empty launch matters: from a few million particles on its 6 us are noise, and a surprise -- the
         // statistic lags by up to 64 steps -- would cost those steps milliseconds each.)
-        const uint32_t ogrid = (N.quiet_steps > 96 && c->n <= (4ull << 20)) ? 128u : 1024u;
+        const uint32_t ogrid = (N.dense_quiet > 96 && c->n <= (4ull << 20)) ? 128u : 1024u;
 #ifdef GPE_TILE_STAMPS
         A.stamps += 64;
 #endif

@@ -694,6 +694,36 @@ def test_half_tiles_take_what_runs_over_the_direct_slot_form(gpe, oracle):
     a.close(); b.close(); sim.close()
 
 
+def test_more_hinted_tiles_than_the_front_workgroups_take(gpe):
+    """A patch of 7 x 7 tiles at 1.9 x the benchmark density in the 1 M cloud: 36 and more tiles run over the direct-slot
+    form, fewer than 2 % of the 2610 -- the first 32 are redone as halves by the dense launch's front workgroups from the
+    second step on (they registered themselves: kCtlHints), the others go through the half-tile launch behind it, step
+    after step; a re-sort in between drops the hints.  Bit-identical to a run without half tiles and hints."""
+    n = 1_000_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=31)
+    rng = np.random.default_rng(32)
+    side = np.float32(7 * 32 * 1.1)
+    extra = int(0.9 * 0.3131 * float(side) ** 2)
+    patch = (np.array([1200.0, 400.0], np.float32) + rng.random((extra, 2), dtype=np.float32) * side).astype(np.float32)
+    pos = np.concatenate([pos, patch]).astype(np.float32)
+    rad = np.full(len(pos), 0.5, np.float32)
+    g = (3.0, -9.81)
+    a = gpe.State(pos, rad, world=world, gravity=g)
+    b = gpe.State(pos, rad, world=world, gravity=g, flags=gpe._lib.FLAG_NO_HALF_TILES)
+    over = []
+    for s in range(24):
+        rs = s in (0, 13)
+        a.update(1 / 60, resort=rs); b.update(1 / 60, resort=rs)
+        a.ctx.sync()
+        over.append(a.ctx.pipeline_info()["overflow_tiles"])
+        if s % 4 == 3:
+            assert np.array_equal(a.positions(), b.positions()), "step %d" % s
+    assert np.array_equal(a.previous_positions(), b.previous_positions())
+    assert max(over) > 32 and a.ctx.pipeline_info()["compat_steps"] == 0, over
+    a.close(); b.close()
+
+
 def test_stragglers_flying_into_empty_space_are_not_lost(gpe, oracle):
     """A few very fast particles shot out of a compact cloud into an otherwise empty world: their tiles look nothing up
     (no block of the kept table lies near them), so they exist for those tiles only through the straggler lists.  Exact
