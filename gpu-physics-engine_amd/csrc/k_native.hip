@@ -3863,10 +3863,13 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
             // travels in the roster header the tile loads anyway), and only while tiles have run over lately (lagged
             // statistic, hinted tiles included): the kernel that carries the front workgroups is 3 % slower than the
             // plain one.  Until it is launched a registered tile simply tries itself again.
-            if (A.roster_hdr != nullptr && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0) {
+            // (Up to 8 M particles, and while the front workgroups can take at least half of the tiles that run over: the
+            // 3 % are 1.5 us of the 1 M launch, against ~20 us of half-tile launch behind it, but 0.1 ms at 100 M.)
+            if (A.roster_hdr != nullptr && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0 && c->n <= (8ull << 20)) {
                 A.hints_on = 1u;
-                if (N.host_stat[kStatOverflow] != 0) N.hint_quiet = 0; else if (N.hint_quiet < 0xFFFFFFFFu) ++N.hint_quiet;
-                if (N.hint_quiet < 32u) A.front_wgs = 2u * kHintMax;
+                const uint32_t over = N.host_stat[kStatOverflow];
+                if (over != 0 && over <= 2u * kHintMax) N.hint_quiet = 0; else if (N.hint_quiet < 0xFFFFFFFFu) ++N.hint_quiet;
+                if (N.hint_quiet < 32u && over <= 2u * kHintMax) A.front_wgs = 2u * kHintMax;
             }
             if (A.front_wgs)
                 hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512, true>), dim3(grid + A.front_wgs), dim3(512), 0, c->stream, A);
