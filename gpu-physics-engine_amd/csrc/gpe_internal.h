@@ -334,6 +334,7 @@ struct NativeState {
     uint32_t step_seq = 0;           // native_prepare_step calls: its parity selects the per-step control words
     uint32_t collide_seq = 0;        // native_collide calls: numbers the dense launches for the tile hints (k_native.hip kCtlHints)
     uint32_t hint_quiet = 0xFFFFFFFFu; // native steps since a tile last ran over, hinted ones included (lagged): the dense launch's front workgroups
+    uint32_t new_streak = 0;         // consecutive native steps whose (lagged) list 1 was not empty
     uint32_t dense_quiet = 0;        // native steps since list 1 or list 2 last had an entry (lagged): the over-capacity launch's grid
     const uint32_t *fresh_word = nullptr;   // tile_ctl word the tiles of the current step read (did the passes run?)
     uint32_t reason = GPE_REASON_NO_PARTICLES;   // why the native kernels do not run (GPE_REASON_*), NONE when they do

@@ -96,7 +96,8 @@ constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every
 // workgroups of the dense launch redo it as two 32x16 halves while the others resolve their tiles: nothing waits behind
 // the dense launch for it (the half-tile launch there cost the 1 M step ~20 us from step ~1000 of the benchmark run on).
 // The tile's own workgroup sees the number in the header it loads anyway and returns; the half workgroup registers the
-// tile again unless the table was re-sorted (the tile then runs over once more and registers itself).  Launches are
+// tile again, kHintAge launches long -- then the tile tries itself once (it may fit again) and, if it still runs over, is
+// registered afresh by the launch that takes it off list 1.  Launches are
 // numbered by native_collide itself (not by step: a host may collide twice on one grid); the list a launch has used is
 // cleared behind it by its over-capacity launch.  Exact whatever the lists hold: a tile is skipped by its own workgroup
 // iff its header carries this launch's number or the next one's (registered again already, by a front workgroup -- or by
@@ -104,6 +105,7 @@ constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every
 constexpr int kCtlHints = 11;                  // [launch parity] tiles registered for the launch of that parity
 constexpr int kCtlHintsSeen = 13;              // hinted tiles of the last launch (statistics)
 constexpr uint32_t kHintMax = 32;
+constexpr uint32_t kHintAge = 240;             // a hint entry: age << 22 | ty << 11 | tx (at most 2048 tiles per axis: 16-bit cells)
 constexpr int kCtlError = 8;                   // sticky
 // Two words each, indexed by the parity of the step (native_prepare_step counts them): a step's hash kernel clears
 // the NEXT step's word while its own is being set, so no workgroup of a launch races with another's reset.
@@ -2965,13 +2967,13 @@ static uint32_t dense_launch_grid(uint32_t tiles_x, uint32_t tiles_y, uint32_t b
 #define GPE_CAP_HALF_FRONT 1392                 // a half redone by the dense launch's front workgroups (kCtlHints): the tile's LDS
 #endif
 // Registers a tile that ran over for the front workgroups of the next step's dense launch (kCtlHints).
-__device__ __forceinline__ void hint_tile(const CollideArgs &A, const int tx, const int ty)
+__device__ __forceinline__ void hint_tile(const CollideArgs &A, const int tx, const int ty, const uint32_t age = 0u)
 {
-    if (A.hints_on == 0u || !A.tb.holds(tx, ty)) return;
+    if (A.hints_on == 0u || !A.tb.holds(tx, ty) || (uint32_t)tx >= 2048u || (uint32_t)ty >= 2048u) return;
     const uint32_t next = A.hint_parity ^ 1u;
     const uint32_t k = atomicAdd(&A.tile_ctl[kCtlHints + next], 1u);
     if (k >= kHintMax) return;
-    A.hints[next * kHintMax + k] = ((uint32_t)ty << 16) | (uint32_t)tx;
+    A.hints[next * kHintMax + k] = (age << 22) | ((uint32_t)ty << 11) | (uint32_t)tx;
     A.roster_hdr[A.tb.index(tx, ty)].w = A.step_stamp + 1u;
 }
 
@@ -2995,11 +2997,11 @@ __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
             const uint32_t count = min(A.tile_ctl[kCtlHints + A.hint_parity], kHintMax);
             if ((wg >> 1) >= count) return;
             const uint32_t tile = A.hints[A.hint_parity * kHintMax + (wg >> 1)];
-            const int htx = (int)(tile & 0xFFFFu), hty = (int)(tile >> 16);
+            const int htx = (int)(tile & 0x7FFu), hty = (int)((tile >> 11) & 0x7FFu);
+            const uint32_t age = tile >> 22;
             if (!A.tb.holds(htx, hty)) return;
             const uint32_t hinted_for = A.roster_hdr[A.tb.index(htx, hty)].w;   // (not registered for this launch: its own workgroup takes it)
             if (hinted_for != A.step_stamp && hinted_for != A.step_stamp + 1u) return;
-            const bool fresh = *A.fresh != 0u;
             const int hy = hty * 2 + (int)(wg & 1u);
             const bool done = process_tile_direct<false>(*reinterpret_cast<Half *>(&S), A, htx, hy);
             if (threadIdx.x == 0) {
@@ -3008,8 +3010,8 @@ __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
                     if (slot < 2u * A.overflow1_cap) A.overflow2[slot] = ((uint32_t)hy << 16) | (uint32_t)htx;
                     else atomicOr(&A.tile_ctl[kCtlError], kErrTileOverflow);
                 }
-                // again on the next step -- unless the table was re-sorted: the tile then tries itself first
-                if ((wg & 1u) == 0u && !fresh) hint_tile(A, htx, hty);
+                // again in the next launch, kHintAge launches long
+                if ((wg & 1u) == 0u && age + 1u < kHintAge) hint_tile(A, htx, hty, age + 1u);
             }
             return;
         }
@@ -3899,7 +3901,12 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         // (A scene in which more than 2 % of the tiles run over has its dense launch on counting-sort tiles by then --
         // `crowded` above: this launch is for the few tiles of a clumped cloud, not for piles; keeping the direct-slot form
         // with halves behind it up to 50 % of the tiles was measured: step 2000 of the 100 M soak 35.5 instead of 31.0 ms.)
-        if (direct_form && N.quiet_steps < 32u && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0) {
+        // (With front workgroups in the dense launch list 1 only holds tiles that ran over for the FIRST time -- one every
+        // ~60 steps in the clumped 1 M cloud, which no lagged statistic foresees: the over-capacity launch takes those as
+        // quarters, and the half-tile launch comes back when list 1 stays occupied, i.e. the hints are full.)
+        if (N.host_stat[kStatOverflowNew] != 0) { if (N.new_streak < 0xFFFFFFFFu) ++N.new_streak; } else N.new_streak = 0;
+        const bool halves_wanted = A.front_wgs ? N.new_streak >= 4u : N.quiet_steps < 32u;
+        if (direct_form && halves_wanted && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0) {
             A.quarters_of_halves = 1u;
             const uint32_t hgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, 2ull * N.host_stat[A.front_wgs ? kStatOverflowNew : kStatOverflow] + 32));
             if (A.order_keys)
@@ -3910,7 +3917,10 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
         }
         // (Only where the empty launch matters: from a few million particles on its 6 us are noise, and a surprise -- the
         // statistic lags by up to 64 steps -- would cost those steps milliseconds each.)
-        const uint32_t ogrid = (N.dense_quiet > 96 && c->n <= (4ull << 20)) ? 128u : 1024u;
+        // ... or, with front workgroups, while the lists have held few work items lately (a first-time tile is four)
+        const uint64_t items = 4ull * N.host_stat[kStatOverflowNew] + 2ull * N.host_stat[kStatHalvesOver];
+        const bool small_grid = c->n <= (4ull << 20) && (N.dense_quiet > 96 || (A.front_wgs != 0u && items <= 128u));
+        const uint32_t ogrid = small_grid ? 128u : 1024u;
 #ifdef GPE_TILE_STAMPS
         A.stamps += 64;
 #endif

@@ -1,4 +1,5 @@
-"""Per-scope GPU time of the native step for one particle count: python scripts/time_step.py N [steps] [gravity]."""
+"""Per-scope GPU time of the native step for one particle count: python scripts/time_step.py N [steps] [gravity] [flags]
+(TIME_STEP_SKIP=k in the environment: advance k steps first)."""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gpe = importlib.import_module("gpu-physics-engine_amd")
@@ -9,6 +10,8 @@ world = gpe.scenes.world_for(n)
 pos, rad = gpe.scenes.uniform_cloud(n, world, seed=0x5EED)
 st = gpe.State(pos, rad, world=world, gravity=grav, mode=gpe.MODE_NATIVE, flags=flags)
 st.run(1 / 60, 10, resort_every=240, resort_first=True)
+skip = int(os.environ.get("TIME_STEP_SKIP", "0"))             # steps to advance before anything is timed (a clumped cloud: 1600)
+if skip: st.run(1 / 60, skip, resort_every=240, resort_first=False)
 st.ctx.sync()
 t0 = time.perf_counter()
 st.run(1 / 60, steps, resort_every=240, resort_first=False)
