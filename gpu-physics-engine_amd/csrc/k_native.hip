@@ -104,7 +104,7 @@ constexpr int kCtlPerStepWords = 8;            // words [0, 8) are cleared every
 // itself, which is past the test), and a front workgroup takes a listed tile iff the header carries one of the two.
 constexpr int kCtlHints = 11;                  // [launch parity] tiles registered for the launch of that parity
 constexpr int kCtlHintsSeen = 13;              // hinted tiles of the last launch (statistics)
-constexpr uint32_t kHintMax = 32;
+constexpr uint32_t kHintMax = 64;
 constexpr uint32_t kHintAge = 240;             // a hint entry: age << 22 | ty << 11 | tx (at most 2048 tiles per axis: 16-bit cells)
 constexpr int kCtlError = 8;                   // sticky
 // Two words each, indexed by the parity of the step (native_prepare_step counts them): a step's hash kernel clears
@@ -2444,6 +2444,12 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
     for (int i = tid; i < (NZ + 1) / 2; i += NT) S.cntw[i] = 0;
     if (tid < 12) S.lcnt[tid] = 0;
     const bool stale = __builtin_amdgcn_readfirstlane((int)fresh_word) == 0;
+    if constexpr (kRoster && HINTS) {
+        // A hinted tile (kCtlHints): two of the launch's first workgroups redo it as halves.  (In front of every other way
+        // out: a sharded tile must not be taken twice -- it would pack its particles twice.)
+        const uint32_t hinted_for = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.w);
+        if (rosters && A.front_wgs != 0u && (hinted_for == A.step_stamp || hinted_for == A.step_stamp + 1u)) return true;
+    }
     if constexpr (ORD) {
         // a ghost list ran over this step: the ghosts come through their block table, which only the counting-sort
         // windows of the over-capacity launch look up -- hand the tile on (a crowded border; the host's `crowded` policy
@@ -2451,11 +2457,6 @@ __device__ __forceinline__ bool process_tile_direct(L &S, const CollideArgs &A, 
         if (A.gho_count == nullptr || __builtin_amdgcn_readfirstlane((int)gsort_word) != 0) return false;
     }
     const uint32_t stamp_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorts_word) + 1u;
-    if constexpr (kRoster && HINTS) {
-        // a hinted tile (kCtlHints): two of the launch's first workgroups redo it as halves
-        const uint32_t hinted_for = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.w);
-        if (rosters && A.front_wgs != 0u && (hinted_for == A.step_stamp || hinted_for == A.step_stamp + 1u)) return true;
-    }
     // (scalar) the roster is of the table in use: no lookup
     const bool listed = rosters && stale && (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y) == stamp_now;
     const bool record = rosters && !listed && A.roster_write != 0u;
@@ -2966,6 +2967,9 @@ static uint32_t dense_launch_grid(uint32_t tiles_x, uint32_t tiles_y, uint32_t b
 #ifndef GPE_CAP_HALF_FRONT
 #define GPE_CAP_HALF_FRONT 1392                 // a half redone by the dense launch's front workgroups (kCtlHints): the tile's LDS
 #endif
+#ifndef GPE_CAP_HALF_FRONT_ORD
+#define GPE_CAP_HALF_FRONT_ORD 1192             // ... of an order-key (sharded) run: 21 bytes per particle in 40 748
+#endif
 // Registers a tile that ran over for the front workgroups of the next step's dense launch (kCtlHints).
 __device__ __forceinline__ void hint_tile(const CollideArgs &A, const int tx, const int ty, const uint32_t age = 0u)
 {
@@ -2982,12 +2986,11 @@ __device__ __forceinline__ void hint_tile(const CollideArgs &A, const int tx, co
 template <int TX, int CAP, bool ORD, int NT, bool HINTS = false>
 __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
 {
-    static_assert(!(HINTS && ORD), "hints: plain runs only");
     // (The half-tile form of the hinted tiles lives in the tile's own LDS: 40 928 bytes, four workgroups per CU, hold a
     // half of 1392 particles -- 59 % of a tile's window at 1.5 x its capacity; the half-tile launch's 2000 would make it
     // 51 KB and three per CU: 54.2 instead of 47.8 us at 1 M, profiles/r04/ab_hints_bisect.txt.)
     struct NoHalf { char unused; };
-    using Half = typename std::conditional<HINTS, TileDirect<32, 16, GPE_CAP_HALF_FRONT, false, 512>, NoHalf>::type;
+    using Half = typename std::conditional<HINTS, TileDirect<32, 16, ORD ? GPE_CAP_HALF_FRONT_ORD : GPE_CAP_HALF_FRONT, ORD, 512>, NoHalf>::type;
     __shared__ TileDirect<TX, 32, CAP, ORD, NT> S;
     static_assert(sizeof(Half) <= sizeof(S) && alignof(Half) <= alignof(TileDirect<TX, 32, CAP, ORD, NT>), "the half form fits the tile's LDS");
     uint32_t wg = blockIdx.x;
@@ -3003,7 +3006,7 @@ __global__ __launch_bounds__(NT, 8) void k_collide_direct(CollideArgs A)
             const uint32_t hinted_for = A.roster_hdr[A.tb.index(htx, hty)].w;   // (not registered for this launch: its own workgroup takes it)
             if (hinted_for != A.step_stamp && hinted_for != A.step_stamp + 1u) return;
             const int hy = hty * 2 + (int)(wg & 1u);
-            const bool done = process_tile_direct<false>(*reinterpret_cast<Half *>(&S), A, htx, hy);
+            const bool done = process_tile_direct<ORD>(*reinterpret_cast<Half *>(&S), A, htx, hy);
             if (threadIdx.x == 0) {
                 if (!done) {
                     const uint32_t slot = atomicAdd(&A.tile_ctl[kCtlOverflow2], 1u);
@@ -3676,6 +3679,22 @@ bool native_should_run(gpe_ctx *c)
     return false;
 }
 
+// Hinted tiles (kCtlHints): the dense launch's first workgroups redo them as halves.  With rosters only (the hint travels
+// in the roster header the tile loads anyway), and only while tiles have run over lately (lagged statistic, hinted tiles
+// included): the kernel that carries the front workgroups is 3 % slower than the plain one.  Until it is launched a
+// registered tile simply tries itself again.  (Up to 8 M particles, and while the front workgroups can take at least half
+// of the tiles that run over: the 3 % are 1.5 us of the 1 M launch, against ~20 us of half-tile launch behind it, but
+// 0.1 ms at 100 M.)
+static void native_hint_policy(gpe_ctx *c, CollideArgs *A)
+{
+    NativeState &N = c->native;
+    if (A->roster_hdr == nullptr || (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) != 0 || c->n > (8ull << 20) || !N.host_stat) return;
+    A->hints_on = 1u;
+    const uint32_t over = N.host_stat[kStatOverflow];
+    if (over != 0 && over <= 2u * kHintMax) N.hint_quiet = 0; else if (N.hint_quiet < 0xFFFFFFFFu) ++N.hint_quiet;
+    if (N.hint_quiet < 32u && over <= 2u * kHintMax) A->front_wgs = 2u * kHintMax;
+}
+
 // pos_in (step-start positions) -> pos_out (after the four colour passes), every particle written.
 gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, const VerletParams *verlet)
 {
@@ -3858,21 +3877,15 @@ gpe_status native_collide(gpe_ctx *c, const float2 *pos_in, float2 *pos_out, con
                     hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(igrid), dim3(512), 0, c->stream, A);
                 }
             }
-            if (!split)
-                hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
-        } else {
-            // Hinted tiles (kCtlHints): the launch's first workgroups redo them as halves.  With rosters only (the hint
-            // travels in the roster header the tile loads anyway), and only while tiles have run over lately (lagged
-            // statistic, hinted tiles included): the kernel that carries the front workgroups is 3 % slower than the
-            // plain one.  Until it is launched a registered tile simply tries itself again.
-            // (Up to 8 M particles, and while the front workgroups can take at least half of the tiles that run over: the
-            // 3 % are 1.5 us of the 1 M launch, against ~20 us of half-tile launch behind it, but 0.1 ms at 100 M.)
-            if (A.roster_hdr != nullptr && (c->cfg.flags & GPE_FLAG_NO_HALF_TILES) == 0 && c->n <= (8ull << 20)) {
-                A.hints_on = 1u;
-                const uint32_t over = N.host_stat[kStatOverflow];
-                if (over != 0 && over <= 2u * kHintMax) N.hint_quiet = 0; else if (N.hint_quiet < 0xFFFFFFFFu) ++N.hint_quiet;
-                if (N.hint_quiet < 32u && over <= 2u * kHintMax) A.front_wgs = 2u * kHintMax;
+            if (!split) {
+                native_hint_policy(c, &A);
+                if (A.front_wgs)
+                    hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512, true>), dim3(grid + A.front_wgs), dim3(512), 0, c->stream, A);
+                else
+                    hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT_ORD, true, 512>), dim3(grid), dim3(512), 0, c->stream, A);
             }
+        } else {
+            native_hint_policy(c, &A);
             if (A.front_wgs)
                 hipLaunchKernelGGL((k_collide_direct<32, GPE_CAP_DIRECT, false, 512, true>), dim3(grid + A.front_wgs), dim3(512), 0, c->stream, A);
             else

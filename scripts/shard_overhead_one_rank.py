@@ -57,3 +57,4 @@ print("flags %d: " % flags, end="")
 print("n=%d  plain %.4f ms/step   sharded loop (RCCL self exchange, %d KB segment) %.4f ms/step   overhead %.1f us" %
       (n, t_plain * 1e3, words * 4 // 1024, t_shard * 1e3, (t_shard - t_plain) * 1e6))
 print("   " + "  ".join("%s %.1fus" % (k, v[0] / max(1, v[1]) * 1e3) for k, v in sorted(tim.items(), key=lambda kv: -kv[1][0])))
+print("   ", ctx.pipeline_info())
