@@ -83,7 +83,8 @@ enum {
     GPE_FLAG_XCD_EIGHTHS = 64u,      /* NATIVE: every XCD works through one contiguous eighth of the tile rows       */
                                      /* (rounds 1-3) instead of interleaved bands of rows; for A/B timing            */
     GPE_FLAG_NO_HALF_TILES = 128u,   /* NATIVE: tiles the direct-slot launch hands on go straight to the 16x16 / 8x8 */
-                                     /* windows (rounds 1-3), not first through 32x16 direct-slot halves; A/B timing */
+                                     /* windows (rounds 1-3), not first through 32x16 direct-slot halves -- neither  */
+                                     /* the half-tile launch nor the dense launch's front workgroups; A/B timing     */
     GPE_FLAG_SHARD_OVERLAP = 256u,   /* sharded runs: the neighbour exchange on a stream of its own beside the       */
                                      /* interior tiles, the tiles along the rank's border first (off by default: on  */
                                      /* one GPU the two cross-stream waits cost more than the exchange they hide)    */
