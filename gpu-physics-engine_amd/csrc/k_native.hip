@@ -3304,7 +3304,9 @@ static gpe_status native_prepare_step(gpe_ctx *c, uint32_t **sorted_ids, bool al
     {
         Scope s(c, "native/hash");
         // at least 4 keys per lane (measured: profiles/r01/tune_hash.txt)
-        const int grid = (int)std::min<uint64_t>(kHashGridMax, std::max<uint64_t>(1, n / (4ull * kHashBlock)));
+        // (two particles per thread until the grid is full: 14.0 against 14.3 us at 1 M with four, 15.2 with one --
+        // the kernel is launch and latency there; from 4 M particles on the grid is kHashGridMax either way)
+        const int grid = (int)std::min<uint64_t>(kHashGridMax, std::max<uint64_t>(1, n / (2ull * kHashBlock)));
         const uint32_t *n_valid = (c->shard.on && c->shard.active) ? c->shard.counts_now() + kShardTotal : nullptr;
         const uint64_t div_magic = ((1ull << 40) + (uint64_t)N.blocks_x - 1) / (uint64_t)N.blocks_x;
         const auto hash_kernel = kept_sharded ? k_native_hash<true> : k_native_hash<false>;
