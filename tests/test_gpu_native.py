@@ -724,6 +724,41 @@ def test_more_hinted_tiles_than_the_front_workgroups_take(gpe):
     a.close(); b.close()
 
 
+def test_hinted_tiles_when_a_host_collides_twice_on_one_grid(gpe):
+    """Tiles that ran over are registered for the NEXT collide launch (kCtlHints: numbered by launch, not by step).  A
+    host that calls the modules one by one may solve collisions twice on one grid build, or build grids without
+    colliding: the registered tiles must be taken exactly once by every launch.  NATIVE against COMPAT, same calls."""
+    n = 200_000
+    world = gpe.scenes.world_for(n)
+    pos, rad = gpe.scenes.uniform_cloud(n, world, seed=51)
+    rng = np.random.default_rng(52)
+    side = np.float32(3 * 32 * 1.1)
+    extra = int(0.9 * 0.3131 * float(side) ** 2)
+    patch = (np.array([500.0, 200.0], np.float32) + rng.random((extra, 2), dtype=np.float32) * side).astype(np.float32)
+    pos = np.concatenate([pos, patch]).astype(np.float32)
+    rad = np.full(len(pos), 0.5, np.float32)
+    g = (1.0, -9.81)
+    a = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_NATIVE)
+    b = gpe.State(pos, rad, world=world, gravity=g, mode=gpe.MODE_COMPAT)
+    both = (a, b)
+    for st in both:
+        st.run(1 / 60, 6, resort_every=0, resort_first=True)            # the patch's tiles run over and register
+    for rep in range(3):
+        for st in both:
+            st.grid.update(); st.collision_system.solve_collisions(); st.collision_system.solve_collisions()
+            st.particles.update_positions(1 / 60)
+            st.grid.update(); st.grid.update(); st.collision_system.solve_collisions(); st.particles.update_positions(1 / 60)
+            st.update(1 / 60)
+        assert np.array_equal(a.positions(), b.positions()), "after round %d of module calls" % rep
+    for st in both:
+        st.run(1 / 60, 6, resort_every=0, resort_first=False)
+    assert np.array_equal(a.positions(), b.positions())
+    assert np.array_equal(a.previous_positions(), b.previous_positions())
+    info = a.ctx.pipeline_info()
+    assert info["compat_steps"] == 0 and info["overflow_tiles"] > 0, info
+    a.close(); b.close()
+
+
 def test_stragglers_flying_into_empty_space_are_not_lost(gpe, oracle):
     """A few very fast particles shot out of a compact cloud into an otherwise empty world: their tiles look nothing up
     (no block of the kept table lies near them), so they exist for those tiles only through the straggler lists.  Exact
